@@ -1,0 +1,210 @@
+/*
+ * include/zkdl_amd.h -- C ABI of libzkdl_amd.so, the MI355X (gfx950) implementation of the zkDL
+ * proving hot path.  Plain pointers and sizes only; every call returns an int status and never
+ * throws.  The reference (SafeAILab/zkDL) has no FFI layer: its boundary is the C++ class API of
+ * fr-tensor.cuh / g1-tensor.cuh / proof.cuh / commitment.cuh / zkfc.cuh / zkrelu.cuh.  Each entry
+ * point below names the reference interface it replaces; zkdl_amd/host/ *.hpp rebuilds those C++
+ * classes (same names, argument meaning and error behaviour) on top of this ABI, and
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - POD element types are byte-compatible with the reference's Fr_t / Fp_t / G1Affine_t /
+ *    G1Jacobian_t (bls12-381.cuh:120,222,419-430): little-endian uint32 limbs, Montgomery form.
+ *  - Pointers named *_d are DEVICE pointers (from zk_malloc or any hipMalloc'd memory), 16-byte
+ *    aligned; pointers named *_h are HOST pointers.  Challenge vectors are host arrays, LSB-first
+ *    (u[0] folds index bit 0), exactly like the reference's vector<Fr_t> arguments.
+ *  - All work is enqueued on the context's HIP stream.  Calls that return values to the host
+ *    synchronise that stream; calls that only write device memory do not.
+ *  - Shape violations return ZK_ERR_SHAPE where the reference throws
+ *    std::runtime_error("Incompatible dimensions ...").
+ */
+#ifndef ZKDL_AMD_H
+#define ZKDL_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { uint32_t v[8]; } zk_fr;        /* Fr_t          (fr-tensor.cuh:13) */
+typedef struct { uint32_t v[12]; } zk_fp;       /* Fp_t          (g1-tensor.cuh:10) */
+typedef struct { zk_fp x, y; } zk_g1a;          /* G1Affine_t    (fr-tensor.cuh:14) */
+typedef struct { zk_fp x, y, z; } zk_g1j;       /* G1Jacobian_t  (fr-tensor.cuh:15) */
+
+typedef struct zk_ctx zk_ctx;                   /* device + stream + pools + RNG */
+typedef struct zk_fc zk_fc;                     /* zkFC   (zkfc.cuh:16-33)   */
+typedef struct zk_relu zk_relu;                 /* zkReLU (zkrelu.cuh:10-20) */
+typedef struct zk_transcript zk_transcript;     /* proof values the reference computes and drops */
+
+enum {
+  ZK_OK = 0,
+  ZK_ERR_SHAPE = 1,   /* reference: throw std::runtime_error("Incompatible dimensions...") */
+  ZK_ERR_ALLOC = 2,   /* reference: silent nullptr from cudaMalloc (fr-tensor.cu:94)        */
+  ZK_ERR_DEVICE = 3,  /* reference: ignored CUDA error, printed at exit (demo.cu:141)        */
+  ZK_ERR_ARG = 4,     /* null / misaligned pointer, bad enum                                */
+  ZK_ERR_RANGE = 5    /* value outside the domain the reference leaves undefined (App. D)   */
+};
+
+/* ---------------------------------------------------------------- context, memory */
+int zk_ctx_create(int device, zk_ctx** out);
+int zk_ctx_destroy(zk_ctx* ctx);
+int zk_ctx_sync(zk_ctx* ctx);
+const char* zk_last_error(const zk_ctx* ctx);     /* message of the last non-OK status */
+const char* zk_version(void);
+void* zk_ctx_stream(zk_ctx* ctx);                 /* the hipStream_t, for callers that interleave */
+/* cudaMalloc / cudaFree / cudaMemcpy in FrTensor and G1Tensor ctors (fr-tensor.cu:92-120) */
+int zk_malloc(zk_ctx* ctx, size_t bytes, void** out_d);
+int zk_free(zk_ctx* ctx, void* ptr_d);
+int zk_memcpy_h2d(zk_ctx* ctx, void* dst_d, const void* src_h, size_t bytes);
+int zk_memcpy_d2h(zk_ctx* ctx, void* dst_h, const void* src_d, size_t bytes);   /* synchronises */
+int zk_memcpy_d2d(zk_ctx* ctx, void* dst_d, const void* src_d, size_t bytes);
+int zk_memset_zero(zk_ctx* ctx, void* dst_d, size_t bytes);
+
+/* HIP-event timing on the context's stream (bench.py roofline leg) */
+int zk_timer_start(zk_ctx* ctx);
+int zk_timer_stop_ms(zk_ctx* ctx, float* ms_out);  /* synchronises */
+/* per-kernel-family device time accumulated with HIP events when enabled (debug/bench only) */
+int zk_prof_enable(zk_ctx* ctx, int on);
+int zk_prof_reset(zk_ctx* ctx);
+/* writes up to cap entries; names are static strings; returns count in *n */
+int zk_prof_read(zk_ctx* ctx, const char** names, float* ms, uint64_t* launches, uint64_t* bytes, int cap, int* n);
+
+/* ---------------------------------------------------------------- challenges / RNG */
+/* random_vec (proof.cu:3-11) and FrTensor::random (fr-tensor.cu:337-368) draw 8 uniform limbs with
+ * the top limb reduced modulo 1944954707.  Here the stream is a seeded counter-based generator so
+ * runs are reproducible; callers may instead pass their own challenge arrays everywhere. */
+int zk_rng_seed(zk_ctx* ctx, uint64_t seed);
+int zk_random_vec(zk_ctx* ctx, uint32_t len, zk_fr* out_h);              /* random_vec */
+int zk_fr_random(zk_ctx* ctx, zk_fr* out_d, uint32_t n);                  /* FrTensor::random */
+int zk_fr_random_int(zk_ctx* ctx, zk_fr* out_d, uint32_t n, uint32_t num_bits); /* FrTensor::random_int */
+uint32_t zk_ceil_log2(uint32_t num);                                       /* ceilLog2, proof.cu:13-30 */
+
+/* ---------------------------------------------------------------- Fr tensor (fr-tensor.cuh:62-133) */
+int zk_fr_add(zk_ctx* ctx, const zk_fr* a_d, const zk_fr* b_d, zk_fr* out_d, uint32_t n);      /* operator+ / += */
+int zk_fr_sub(zk_ctx* ctx, const zk_fr* a_d, const zk_fr* b_d, zk_fr* out_d, uint32_t n);      /* operator- / -= */
+int zk_fr_mul(zk_ctx* ctx, const zk_fr* a_d, const zk_fr* b_d, zk_fr* out_d, uint32_t n);      /* operator* / *= */
+int zk_fr_neg(zk_ctx* ctx, const zk_fr* a_d, zk_fr* out_d, uint32_t n);                        /* unary -        */
+int zk_fr_add_scalar(zk_ctx* ctx, const zk_fr* a_d, const zk_fr* x_h, zk_fr* out_d, uint32_t n);
+int zk_fr_sub_scalar(zk_ctx* ctx, const zk_fr* a_d, const zk_fr* x_h, zk_fr* out_d, uint32_t n);
+int zk_fr_mul_scalar(zk_ctx* ctx, const zk_fr* a_d, const zk_fr* x_h, zk_fr* out_d, uint32_t n);
+int zk_fr_mont(zk_ctx* ctx, const zk_fr* a_d, zk_fr* out_d, uint32_t n);                       /* mont()   */
+int zk_fr_unmont(zk_ctx* ctx, const zk_fr* a_d, zk_fr* out_d, uint32_t n);                     /* unmont() */
+int zk_fr_sum(zk_ctx* ctx, const zk_fr* a_d, uint32_t n, zk_fr* out_h);                        /* sum()    */
+/* FrTensor::operator()(const vector<Fr_t>&): multilinear evaluation; size must be in (2^(k-1), 2^k] */
+int zk_fr_me(zk_ctx* ctx, const zk_fr* t_d, uint32_t n, const zk_fr* u_h, uint32_t k, zk_fr* out_h);
+/* FrTensor::partial_me: *out_n receives the result length; out_d must hold zk_fr_partial_me_size() */
+uint32_t zk_fr_partial_me_size(uint32_t n, uint32_t k, uint32_t window);
+int zk_fr_partial_me(zk_ctx* ctx, const zk_fr* t_d, uint32_t n, const zk_fr* u_h, uint32_t k, uint32_t window, zk_fr* out_d);
+/* FrTensor::split (fr-tensor.cu:389-397); outputs hold (n+1)/2 elements each */
+int zk_fr_split(zk_ctx* ctx, const zk_fr* t_d, uint32_t n, uint32_t window, zk_fr* out0_d, zk_fr* out1_d);
+
+/* ---------------------------------------------------------------- sumchecks (proof.cuh:13-34) */
+/* proof_h receives 3k+2 (inner product, Hadamard) or 3k+1 (binary) elements */
+int zk_sumcheck_ip(zk_ctx* ctx, const zk_fr* a_d, const zk_fr* b_d, uint32_t n, const zk_fr* u_h, uint32_t k, zk_fr* proof_h);
+int zk_sumcheck_hadamard(zk_ctx* ctx, const zk_fr* a_d, const zk_fr* b_d, uint32_t n, const zk_fr* u_h, const zk_fr* v_h, uint32_t k, zk_fr* proof_h);
+int zk_sumcheck_binary(zk_ctx* ctx, const zk_fr* a_d, uint32_t n, const zk_fr* u_h, const zk_fr* v_h, uint32_t k, zk_fr* proof_h);
+
+/* ---------------------------------------------------------------- G1 tensor (g1-tensor.cuh:76-174) */
+int zk_g1_fill(zk_ctx* ctx, zk_g1j* out_d, uint32_t n, const zk_g1j* g_h);                   /* ctor(size, g)      */
+int zk_g1a_fill(zk_ctx* ctx, zk_g1a* out_d, uint32_t n, const zk_g1a* g_h);
+int zk_g1_from_affine(zk_ctx* ctx, const zk_g1a* a_d, zk_g1j* out_d, uint32_t n);            /* ctor(G1TensorAffine) */
+int zk_g1_neg(zk_ctx* ctx, const zk_g1j* a_d, zk_g1j* out_d, uint32_t n);                    /* unary -            */
+int zk_g1a_neg(zk_ctx* ctx, const zk_g1a* a_d, zk_g1a* out_d, uint32_t n);
+int zk_g1_add(zk_ctx* ctx, const zk_g1j* a_d, const zk_g1j* b_d, zk_g1j* out_d, uint32_t n);  /* + / += (Jacobian)   */
+int zk_g1_sub(zk_ctx* ctx, const zk_g1j* a_d, const zk_g1j* b_d, zk_g1j* out_d, uint32_t n);
+int zk_g1_madd(zk_ctx* ctx, const zk_g1j* a_d, const zk_g1a* b_d, zk_g1j* out_d, uint32_t n); /* + / += (affine)     */
+int zk_g1_msub(zk_ctx* ctx, const zk_g1j* a_d, const zk_g1a* b_d, zk_g1j* out_d, uint32_t n);
+int zk_g1_add_bcast(zk_ctx* ctx, const zk_g1j* a_d, const zk_g1j* x_h, zk_g1j* out_d, uint32_t n);
+int zk_g1_sub_bcast(zk_ctx* ctx, const zk_g1j* a_d, const zk_g1j* x_h, zk_g1j* out_d, uint32_t n);
+int zk_g1_madd_bcast(zk_ctx* ctx, const zk_g1j* a_d, const zk_g1a* x_h, zk_g1j* out_d, uint32_t n);
+int zk_g1_msub_bcast(zk_ctx* ctx, const zk_g1j* a_d, const zk_g1a* x_h, zk_g1j* out_d, uint32_t n);
+/* G1TensorJacobian::sum: reduction tree shaped like the reference's (g1-tensor.cu:368-420), so the
+ * Jacobian limbs match it bit for bit */
+int zk_g1_sum(zk_ctx* ctx, const zk_g1j* a_d, uint32_t n, zk_g1j* out_h);
+/* operator*= (elementwise) and operator* (generators broadcast over m rows): 256-step scalar-muls
+ * on the raw limb bits, as g1-tensor.cu:422-461 */
+int zk_g1_mul(zk_ctx* ctx, const zk_g1j* g_d, const zk_fr* s_d, zk_g1j* out_d, uint32_t n);
+int zk_g1_mul_bcast(zk_ctx* ctx, const zk_g1j* g_d, uint32_t n, const zk_fr* s_d, uint32_t total, zk_g1j* out_d);
+/* G1TensorJacobian::operator()(const vector<Fr_t>&) */
+int zk_g1_me(zk_ctx* ctx, const zk_g1j* t_d, uint32_t n, const zk_fr* u_h, uint32_t k, zk_g1j* out_h);
+/* affine-canonical form (x = X/Z^2, y = Y/Z^3, Montgomery limbs; inf flag, x = y = 0 when Z == 0):
+ * the build's definition of G1 parity -- the reference never normalises */
+int zk_g1_to_affine(zk_ctx* ctx, const zk_g1j* a_d, uint32_t n, zk_g1a* out_d, uint8_t* inf_d);
+
+/* ---------------------------------------------------------------- commitment (commitment.cuh:8-23) */
+/* MSM algorithm selection for commit/open. LITERAL = the reference's op sequence (one 256-step
+ * double-and-add per pair, reference-shaped sums); PIPPENGER = bucket method (same group elements,
+ * different Jacobian representatives). */
+enum { ZK_MSM_LITERAL = 0, ZK_MSM_PIPPENGER = 1 };
+int zk_set_msm_mode(zk_ctx* ctx, int mode);
+int zk_set_msm_window(zk_ctx* ctx, uint32_t window_bits);   /* 0 = automatic */
+/* Commitment::commit with the INTENDED row semantics:
+ * out[row] = sum_j gens[j] * unmont(t[row*n + j]);  tn % n == 0, out holds tn/n points */
+int zk_commit(zk_ctx* ctx, const zk_g1j* gens_d, uint32_t n, const zk_fr* t_d, uint32_t tn, zk_g1j* out_d);
+/* Commitment::me_open: proof_h receives 3k+1 points, *ret_h = t(0) */
+int zk_me_open(zk_ctx* ctx, const zk_fr* t_d, const zk_g1j* gens_d, uint32_t n, const zk_fr* u_h, uint32_t k, zk_g1j* proof_h, zk_fr* ret_h);
+/* Commitment::open: com_eval_h = com(u_hi) (computed and dropped by the reference) */
+int zk_open(zk_ctx* ctx, const zk_g1j* gens_d, uint32_t n, const zk_fr* t_d, uint32_t tn, const zk_g1j* com_d, uint32_t m,
+            const zk_fr* u_h, uint32_t k, zk_g1j* com_eval_h, zk_g1j* proof_h, zk_fr* ret_h);
+
+/* ---------------------------------------------------------------- layers */
+/* float_to_Fr_kernel (zkfc.cu:80-88): quantise rows x cols floats (device) into a zero-padded
+ * rows_p x cols_p Fr tensor, 16 fractional bits, NOT yet Montgomery */
+int zk_float_to_fr(zk_ctx* ctx, const float* fs_d, zk_fr* out_d, uint32_t rows, uint32_t rows_p, uint32_t cols, uint32_t cols_p);
+
+/* zkFC (zkfc.cuh:16-33).  weights_d: in*out Montgomery elements, row-major [in][out]; the object
+ * keeps its own copy and commits to it with gens (constructor, zkfc.cu:102-104). */
+int zk_fc_create(zk_ctx* ctx, uint32_t in, uint32_t out, const zk_fr* weights_d, const zk_g1j* gens_d, uint32_t n_gens, zk_fc** out_fc);
+/* zkFC::from_float_gpu_ptr (zkfc.cu:90-100): pads to powers of two, quantises, mont(), commits */
+int zk_fc_from_float(zk_ctx* ctx, uint32_t in, uint32_t out, const float* w_d, const zk_g1j* gens_d, uint32_t n_gens, zk_fc** out_fc);
+int zk_fc_destroy(zk_fc* fc);
+uint32_t zk_fc_in(const zk_fc* fc);
+uint32_t zk_fc_out(const zk_fc* fc);
+uint32_t zk_fc_com_size(const zk_fc* fc);
+const zk_fr* zk_fc_weights(const zk_fc* fc);     /* device pointer */
+const zk_g1j* zk_fc_com(const zk_fc* fc);        /* device pointer, com_size points */
+/* zkFC::load_float_gpu_input (zkfc.cu:106-115) */
+int zk_fc_load_input(zk_ctx* ctx, uint32_t batch, uint32_t in_dim, const float* x_d, zk_fr* out_d);
+/* zkFC::operator() (zkfc.cu:117-126): Z[B x out] = X[B x in] * W; xn % in == 0 */
+int zk_fc_forward(zk_ctx* ctx, const zk_fc* fc, const zk_fr* x_d, uint32_t xn, zk_fr* z_d);
+/* zkFC::prove (zkfc.cu:128-145) with the three challenge vectors made explicit
+ * (k_bs = ceilLog2(batch), k_in = ceilLog2(in), k_out = ceilLog2(out)); appends to tr:
+ *   Fr: [ip sumcheck 3*k_in+2][Z(u_out||u_bs)][me_open return]   G1: [com(u_hi)][me_open 3*log2(n_gens)+1] */
+int zk_fc_prove(zk_ctx* ctx, const zk_fc* fc, const zk_fr* x_d, uint32_t xn, const zk_fr* z_d, uint32_t zn,
+                const zk_g1j* gens_d, uint32_t n_gens, const zk_fr* u_bs_h, const zk_fr* u_in_h, const zk_fr* u_out_h,
+                zk_transcript* tr);
+
+/* zkReLU (zkrelu.cuh:10-20): owns sign / mag_bin / rem_bin produced by the forward pass */
+int zk_relu_create(zk_ctx* ctx, zk_relu** out_relu);
+int zk_relu_destroy(zk_relu* relu);
+/* zkReLU::operator() (zkrelu.cu:44-51): returns ZK_ERR_RANGE (after completing) if any input lies
+ * outside the +-2^47 window where the reference's kernel is undefined */
+int zk_relu_forward(zk_ctx* ctx, zk_relu* relu, const zk_fr* x_d, uint32_t n, zk_fr* z_d);
+/* aux tensors as the reference stores them (one Fr per bit); device pointers valid until the next forward */
+const zk_fr* zk_relu_sign(const zk_relu* relu);
+const zk_fr* zk_relu_mag_bin(const zk_relu* relu);
+const zk_fr* zk_relu_rem_bin(const zk_relu* relu);
+/* zkReLU::prove (zkrelu.cu:79-100); k = ceilLog2(n); challenge lengths k+5,k+5,k+4,k+4,k,k,k; appends
+ *   Fr: [bin(mag) 3(k+5)+1][partial_me(mag,32) 32][bin(rem) 3(k+4)+1][partial_me(rem,16) 16][hadamard 3k+2] */
+int zk_relu_prove(zk_ctx* ctx, const zk_relu* relu, const zk_fr* x_d, const zk_fr* z_d, uint32_t n,
+                  const zk_fr* u_z_h, const zk_fr* v_z_h, const zk_fr* u_r_h, const zk_fr* v_r_h, const zk_fr* u_rec_h,
+                  const zk_fr* u_hp_h, const zk_fr* v_hp_h, zk_transcript* tr);
+
+/* ---------------------------------------------------------------- transcript */
+int zk_transcript_create(zk_ctx* ctx, zk_transcript** out);
+int zk_transcript_destroy(zk_transcript* tr);
+int zk_transcript_reset(zk_transcript* tr);
+/* synchronises; counts of values appended so far */
+int zk_transcript_counts(zk_transcript* tr, size_t* n_fr, size_t* n_g1);
+int zk_transcript_read(zk_transcript* tr, zk_fr* fr_h, size_t fr_cap, zk_g1j* g1_h, size_t g1_cap);
+/* G1 entries in affine-canonical form (inf flags as bytes) */
+int zk_transcript_read_affine(zk_transcript* tr, zk_g1a* g1_h, uint8_t* inf_h, size_t cap);
+/* Fr checksum of the transcript: sum of all Fr entries plus, per G1 entry, its affine x and y limbs
+ * folded into Fr -- the per-proof aggregate that ranks all-reduce in the multi-GPU bench */
+int zk_transcript_digest(zk_transcript* tr, zk_fr* out_h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

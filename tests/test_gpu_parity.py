@@ -1,0 +1,272 @@
+"""GPU parity tests proper: every call goes through the C ABI (libzkdl_amd.so) and is compared with
+the CPU oracle on the same seeded inputs.  Bar: bit-exact Fr; G1 bit-exact in Jacobian limbs for the
+operator-level kernels that keep the reference's association order, affine-canonical otherwise."""
+import numpy as np
+import pytest
+
+from util import rand_fp, rand_fr, rand_points, small_signed_fr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def zk():
+    from zkdl_amd.capi import Zk
+    z = Zk(0)
+    yield z
+    z.close()
+
+
+def eq(a, b):
+    return np.array_equal(np.asarray(a).reshape(-1), np.asarray(b).reshape(-1))
+
+
+# ------------------------------------------------------------------ Fr tensor
+@pytest.mark.parametrize("n", [1, 63, 64, 257, 5000])
+def test_fr_elementwise(zk, oracle, rng, n):
+    a, b = rand_fr(rng, n), rand_fr(rng, n)
+    # edge operands in the first slots: 0, 1, r-1, R mod r
+    c = oracle.constants()
+    edge = np.stack([np.zeros(8, np.uint32), np.eye(1, 8, 0, dtype=np.uint32)[0], oracle.fr_neg(np.eye(1, 8, 0, dtype=np.uint32))[0], c["fr_one"]])
+    m = min(n, 4)
+    a[:m] = edge[:m]
+    b[:m] = edge[::-1][:m]
+    da, db = zk.upload(a), zk.upload(b)
+    assert eq(zk.fr_add(da, db).download(), oracle.fr_add(a, b))
+    assert eq(zk.fr_sub(da, db).download(), oracle.fr_sub(a, b))
+    assert eq(zk.fr_mul(da, db).download(), oracle.fr_mul(a, b))
+    assert eq(zk.fr_neg(da).download(), oracle.fr_neg(a))
+    assert eq(zk.fr_mont(da).download(), oracle.fr_mont(a))
+    assert eq(zk.fr_unmont(da).download(), oracle.fr_unmont(a))
+    x = rand_fr(rng, 1)
+    assert eq(zk.fr_add_scalar(da, x).download(), oracle.fr_add_s(a, x))
+    assert eq(zk.fr_sub_scalar(da, x).download(), oracle.fr_sub_s(a, x))
+    assert eq(zk.fr_mul_scalar(da, x).download(), oracle.fr_mul_s(a, x))
+    assert eq(zk.fr_sum(da), oracle.fr_sum(a))
+
+
+def test_fr_empty_and_shape_errors(zk, rng):
+    from zkdl_amd.capi import ShapeError
+    e = zk.upload(np.zeros((0, 8), np.uint32))
+    assert zk.fr_add(e, e).download().shape[0] == 0
+    assert not zk.fr_sum(e).any()
+    a, b = zk.upload(rand_fr(rng, 4)), zk.upload(rand_fr(rng, 5))
+    with pytest.raises(ShapeError):
+        zk.fr_add(a, b)
+    with pytest.raises(ShapeError):
+        zk.fr_me(a, rand_fr(rng, 3))          # size <= 2^(k-1)
+    with pytest.raises(ShapeError):
+        zk.fr_me(b, rand_fr(rng, 2))          # size > 2^k
+    with pytest.raises(ShapeError):
+        zk.fr_partial_me(a, rand_fr(rng, 2), 4)
+    with pytest.raises(ShapeError):
+        zk.fr_split(a, 4)
+
+
+@pytest.mark.parametrize("n,k", [(1, 0), (2, 1), (5, 3), (64, 6), (1000, 10), (1025, 11), (70000, 17)])
+def test_fr_me(zk, oracle, rng, n, k):
+    t, u = rand_fr(rng, n), rand_fr(rng, k)
+    assert eq(zk.fr_me(zk.upload(t), u), oracle.fr_me(t, u))
+
+
+@pytest.mark.parametrize("n,window,k", [(12, 3, 2), (4096, 1, 5), (40, 8, 3), (2 * 16, 16, 1), (6, 2, 0), (300 * 32, 32, 9), (37 * 5, 5, 6), (3000, 1, 12)])
+def test_fr_partial_me(zk, oracle, rng, n, window, k):
+    t, u = rand_fr(rng, n), rand_fr(rng, k)
+    got = zk.fr_partial_me(zk.upload(t), u, window).download()
+    assert eq(got, oracle.fr_partial_me(t, u, window))
+
+
+def test_fr_split(zk, oracle, rng):
+    t = rand_fr(rng, 37)
+    o0, o1 = zk.fr_split(zk.upload(t), 4)
+    w0, w1 = oracle.fr_split(t, 4)
+    assert eq(o0.download(), w0) and eq(o1.download(), w1)
+
+
+def test_fr_random_is_canonical_and_reproducible(zk):
+    zk.seed(123)
+    a = zk.fr_random(1000).download()
+    v = zk.random_vec(5)
+    zk.seed(123)
+    b = zk.fr_random(1000).download()
+    assert eq(a, b) and eq(v, zk.random_vec(5))
+    assert (a[:, 7] < 1944954707).all() and len({x.tobytes() for x in a}) == 1000
+    r = zk.fr_random_int(256, 8).download()
+    # values are uniform 8-bit ints minus 128, as field elements: either < 128 or >= r - 128
+    small = (r[:, 1:] == 0).all(axis=1)
+    assert (r[small, 0] < 128).all() and (~small).any()
+
+
+# ------------------------------------------------------------------ sumchecks
+@pytest.mark.parametrize("n,k", [(1, 0), (8, 3), (6, 3), (2048, 11), (1500, 11), (5000, 13)])
+def test_sumcheck_ip(zk, oracle, rng, n, k):
+    a, b, u = rand_fr(rng, n), rand_fr(rng, n), rand_fr(rng, k)
+    assert eq(zk.sumcheck_ip(zk.upload(a), zk.upload(b), u), oracle.ip_sumcheck(a, b, u))
+
+
+@pytest.mark.parametrize("n,k", [(1, 0), (8, 3), (7, 3), (4096, 12), (3000, 12), (9000, 14)])
+def test_sumcheck_hadamard(zk, oracle, rng, n, k):
+    a, b, u, v = rand_fr(rng, n), rand_fr(rng, n), rand_fr(rng, k), rand_fr(rng, k)
+    assert eq(zk.sumcheck_hadamard(zk.upload(a), zk.upload(b), u, v), oracle.hp_sumcheck(a, b, u, v))
+
+
+@pytest.mark.parametrize("n,k", [(1, 0), (16, 4), (12, 4), (8192, 13), (5001, 13)])
+def test_sumcheck_binary(zk, oracle, rng, n, k):
+    bits = rng.integers(0, 2, size=n)
+    one = oracle.constants()["fr_one"]
+    a = np.where(bits[:, None] == 1, one[None, :], 0).astype(np.uint32)
+    u, v = rand_fr(rng, k), rand_fr(rng, k)
+    assert eq(zk.sumcheck_binary(zk.upload(a), u, v), oracle.bin_sumcheck(a, u, v))
+    a2 = rand_fr(rng, n)                      # non-boolean table: generic coefficients
+    assert eq(zk.sumcheck_binary(zk.upload(a2), u, v), oracle.bin_sumcheck(a2, u, v))
+
+
+def test_sumcheck_shape_errors(zk, rng):
+    from zkdl_amd.capi import ShapeError
+    a = zk.upload(rand_fr(rng, 4))
+    with pytest.raises(ShapeError):
+        zk.sumcheck_ip(a, a, rand_fr(rng, 3))
+    with pytest.raises(ShapeError):
+        zk.sumcheck_binary(zk.upload(rand_fr(rng, 9)), rand_fr(rng, 3), rand_fr(rng, 3))
+    with pytest.raises(ShapeError):
+        zk.sumcheck_hadamard(a, a, rand_fr(rng, 2), rand_fr(rng, 3))
+
+
+# ------------------------------------------------------------------ G1 tensor (Jacobian-bitwise)
+def test_g1_elementwise_bitwise(zk, oracle, rng):
+    n = 70
+    P, Q = rand_points(oracle, rng, n), rand_points(oracle, rng, n)
+    inf = np.zeros(36, np.uint32)
+    inf[12:24] = oracle.constants()["fp_one"]
+    # special cases: inf + Q, P + inf, P + P, P + (-P)
+    P[0] = inf
+    Q[1] = inf
+    Q[2] = P[2]
+    Q[3] = oracle.g1_neg(P[3:4])[0]
+    dP, dQ = zk.upload(P), zk.upload(Q)
+    assert eq(zk.g1_add(dP, dQ).download(), oracle.g1_add(P, Q))
+    assert eq(zk.g1_sub(dP, dQ).download(), oracle.g1_sub(P, Q))
+    assert eq(zk.g1_neg(dP).download(), oracle.g1_neg(P))
+    assert eq(zk.g1_add_bcast(dP, Q[5]).download(), oracle.g1_add_s(P, Q[5:6]))
+    assert eq(zk.g1_sub_bcast(dP, Q[5]).download(), oracle.g1_sub_s(P, Q[5:6]))
+    aff, flags = oracle.g1_to_affine(Q)
+    aff[1] = aff[4]
+    dA = zk.upload(aff)
+    assert eq(zk.g1_madd(dP, dA).download(), oracle.g1_madd(P, aff))
+    assert eq(zk.g1_msub(dP, dA).download(), oracle.g1_msub(P, aff))
+    assert eq(zk.g1_madd_bcast(dP, aff[7]).download(), oracle.g1_madd_s(P, aff[7:8]))
+    assert eq(zk.g1_msub_bcast(dP, aff[7]).download(), oracle.g1_msub_s(P, aff[7:8]))
+    assert eq(zk.g1_from_affine(dA).download(), oracle.g1_from_affine(aff))
+    assert eq(zk.g1_fill(9, P[8]).download(), np.repeat(P[8:9], 9, axis=0))
+    got_aff, got_inf = zk.g1_to_affine(dP)
+    want_aff, want_inf = oracle.g1_to_affine(P)
+    assert eq(got_aff, want_aff) and eq(got_inf, want_inf) and got_inf[0] == 1
+
+
+@pytest.mark.parametrize("n", [1, 2, 64, 65, 129, 300])
+def test_g1_sum_reference_tree(zk, oracle, rng, n):
+    base = rand_points(oracle, rng, min(n, 40))
+    P = base[np.arange(n) % base.shape[0]]
+    if n > 3:
+        P[3] = oracle.g1_double(P[2:3])[0]
+    assert eq(zk.g1_sum(zk.upload(P)), oracle.g1_sum(P))
+
+
+def test_g1_scalar_mul_and_me(zk, oracle, rng):
+    n = 24
+    P = rand_points(oracle, rng, n)
+    s = rand_fr(rng, n)
+    s[0] = 0
+    s[1] = 0; s[1, 0] = 1
+    s[2] = oracle.constants()["fr_p"]                 # r*P = infinity
+    s[3] = np.full(8, 0xFFFFFFFF, np.uint32)          # all 256 raw bits set (g1-tensor.cu:422-430 uses them all)
+    dP, ds = zk.upload(P), zk.upload(s)
+    assert eq(zk.g1_mul(dP, ds).download(), oracle.g1_mul(P, s))
+    s2 = rand_fr(rng, 3 * 8)
+    assert eq(zk.g1_mul_bcast(zk.upload(P[:8]), zk.upload(s2)).download(), oracle.g1_mul_bcast(P[:8], s2))
+    for m, k in [(1, 0), (2, 1), (6, 3), (8, 3)]:
+        u = rand_fr(rng, k)
+        assert eq(zk.g1_me(zk.upload(P[:m]), u), oracle.g1_me(P[:m], u))
+
+
+# ------------------------------------------------------------------ commitment (literal back end: bitwise)
+def test_commit_me_open_open_literal(zk, oracle, rng):
+    from zkdl_amd.capi import MSM_LITERAL, ShapeError
+    zk.set_msm_mode(MSM_LITERAL)
+    n, m = 8, 4
+    gens = rand_points(oracle, rng, n)
+    t = small_signed_fr(oracle, rng, n * m)
+    dg, dt = zk.upload(gens), zk.upload(t)
+    com = zk.commit(dg, dt)
+    want_com = oracle.commit(gens, t)
+    assert eq(com.download(), want_com)
+    u = rand_fr(rng, 3)
+    tt = rand_fr(rng, n)
+    ret, proof = zk.me_open(zk.upload(tt), dg, u)
+    wret, wproof = oracle.me_open(tt, gens, u)
+    assert eq(ret, wret) and eq(proof, wproof)
+    u5 = rand_fr(rng, 5)
+    ret, ce, proof = zk.open(dg, dt, com, u5)
+    wret, wce, wproof = oracle.open(gens, t, want_com, u5)
+    assert eq(ret, wret) and eq(ce, wce) and eq(proof, wproof)
+    with pytest.raises(ShapeError):
+        zk.commit(dg, zk.upload(rand_fr(rng, 7)))
+
+
+# ------------------------------------------------------------------ layers
+def test_quantiser_matmul_relu(zk, oracle, rng):
+    from zkdl_amd.capi import FC, ReLU
+    B, n_in, n_out = 5, 6, 7
+    W = rng.uniform(-0.4, 0.4, size=(n_in, n_out)).astype(np.float32)
+    W[0, :4] = [0.0, -0.0, 0.5 / 65536, -1.5 / 65536]
+    X = rng.standard_normal((B, n_in)).astype(np.float32)
+    Wq = zk.float_to_fr(zk.upload_f32(W), n_in, 8, n_out, 8)
+    want_Wq = oracle.float_to_fr(W, 8, 8)
+    assert eq(Wq.download(), want_Wq)
+    gens = rand_points(oracle, rng, 8)
+    zk.set_msm_mode(0)
+    fc = FC.from_float(zk, n_in, n_out, zk.upload_f32(W), zk.upload(gens))
+    Wm = oracle.fr_mont(want_Wq)
+    assert eq(fc.weights().download(), Wm) and (fc.n_in, fc.n_out, fc.com_size) == (8, 8, 8)
+    assert eq(fc.com().download(), oracle.commit(gens, Wm))
+    Xq = oracle.fr_mont(oracle.float_to_fr(X, 8, 8))
+    Z = fc.forward(zk.upload(Xq))
+    want_Z = oracle.fc_forward(Xq, Wm, 8, 8, 8)
+    assert eq(Z.download(), want_Z)
+    relu = ReLU(zk)
+    A = relu.forward(Z)
+    wA, wsign, wmag, wrem = oracle.relu_forward(want_Z)
+    sign, mag, rem = relu.aux()
+    assert eq(A.download(), wA) and eq(sign.download(), wsign) and eq(mag.download(), wmag) and eq(rem.download(), wrem)
+
+
+def test_relu_window_edges_and_range_error(zk, oracle):
+    from zkdl_amd.capi import ReLU, ZkError
+    import bigint_model as bm
+    vals = [0, 1, 32767, 32768, 32769, 65536, (1 << 47) - 1, -1, -32768, -32769, -(1 << 47)]
+    X = np.stack([bm.fr_to_mont(v % bm.R_MOD) for v in vals])
+    relu = ReLU(zk)
+    A = relu.forward(zk.upload(X))
+    wA, wsign, wmag, wrem = oracle.relu_forward(X)
+    sign, mag, rem = relu.aux()
+    assert eq(A.download(), wA) and eq(sign.download(), wsign) and eq(mag.download(), wmag) and eq(rem.download(), wrem)
+    bad = np.stack([bm.fr_to_mont(1 << 47)])            # first value outside the window
+    with pytest.raises(ZkError):
+        relu.forward(zk.upload(bad))
+
+
+@pytest.mark.parametrize("dims,batch", [([6, 5, 4], 3), ([16, 32, 8], 4), ([5, 3], 1)])
+def test_mlp_prove_matches_oracle(zk, oracle, dims, batch):
+    from mlp_util import prove_mlp_gpu, prove_mlp_oracle, synth_mlp
+    zk.set_msm_mode(0)
+    model = synth_mlp(oracle, dims, batch, seed=11)
+    fr_o, g1_o = prove_mlp_oracle(oracle, model)
+    fr_g, aff_g, inf_g, info = prove_mlp_gpu(zk, model)
+    assert eq(info["Yhat"], model["_oracle"]["Yhat"])
+    for a, b in zip(info["coms"], model["_oracle"]["coms"]):
+        assert eq(a, b)
+    assert eq(fr_g, fr_o)
+    aff_o, inf_o = oracle.g1_to_affine(g1_o)
+    assert eq(aff_g, aff_o) and eq(inf_g, inf_o)
+    _, g1_g = info["tr"].read()
+    assert eq(g1_g, g1_o)                      # literal back end keeps the reference's Jacobian limbs

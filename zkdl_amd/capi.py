@@ -1,0 +1,527 @@
+"""ctypes binding of libzkdl_amd.so (include/zkdl_amd.h) -- the only way Python reaches the HIP
+kernels.  There is no CPU fallback: if the shared library is missing, or no MI355X is visible,
+construction raises.
+
+Device arrays are thin handles (`DevArray`) over zk_malloc'd memory; numpy arrays cross with
+explicit upload()/download().  Element layouts (uint32 limbs): Fr (n, 8), G1 affine (n, 24),
+G1 Jacobian (n, 36) -- byte-compatible with the reference's Fr_t / G1Affine_t / G1Jacobian_t.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libzkdl_amd.so")
+
+_vp = ctypes.c_void_p
+_u32 = ctypes.c_uint32
+_sz = ctypes.c_size_t
+
+ZK_OK, ZK_ERR_SHAPE, ZK_ERR_ALLOC, ZK_ERR_DEVICE, ZK_ERR_ARG, ZK_ERR_RANGE = range(6)
+MSM_LITERAL, MSM_PIPPENGER = 0, 1
+
+# every symbol include/zkdl_amd.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = """zk_ctx_create zk_ctx_destroy zk_ctx_sync zk_last_error zk_version zk_ctx_stream zk_malloc zk_free
+zk_memcpy_h2d zk_memcpy_d2h zk_memcpy_d2d zk_memset_zero zk_timer_start zk_timer_stop_ms zk_prof_enable zk_prof_reset
+zk_prof_read zk_rng_seed zk_random_vec zk_fr_random zk_fr_random_int zk_ceil_log2 zk_fr_add zk_fr_sub zk_fr_mul zk_fr_neg
+zk_fr_add_scalar zk_fr_sub_scalar zk_fr_mul_scalar zk_fr_mont zk_fr_unmont zk_fr_sum zk_fr_me zk_fr_partial_me_size
+zk_fr_partial_me zk_fr_split zk_sumcheck_ip zk_sumcheck_hadamard zk_sumcheck_binary zk_g1_fill zk_g1a_fill
+zk_g1_from_affine zk_g1_neg zk_g1a_neg zk_g1_add zk_g1_sub zk_g1_madd zk_g1_msub zk_g1_add_bcast zk_g1_sub_bcast
+zk_g1_madd_bcast zk_g1_msub_bcast zk_g1_sum zk_g1_mul zk_g1_mul_bcast zk_g1_me zk_g1_to_affine zk_set_msm_mode
+zk_set_msm_window zk_commit zk_me_open zk_open zk_float_to_fr zk_fc_create zk_fc_from_float zk_fc_destroy zk_fc_in
+zk_fc_out zk_fc_com_size zk_fc_weights zk_fc_com zk_fc_load_input zk_fc_forward zk_fc_prove zk_relu_create
+zk_relu_destroy zk_relu_forward zk_relu_sign zk_relu_mag_bin zk_relu_rem_bin zk_relu_prove zk_transcript_create
+zk_transcript_destroy zk_transcript_reset zk_transcript_counts zk_transcript_read zk_transcript_read_affine
+zk_transcript_digest""".split()
+
+
+class ZkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+class ShapeError(ZkError, ValueError):
+    """The reference's std::runtime_error("Incompatible dimensions ...")."""
+
+
+def load_library():
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libzkdl_amd.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                           "there is no CPU fallback for the proving path")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.zk_last_error.restype = ctypes.c_char_p
+    lib.zk_version.restype = ctypes.c_char_p
+    lib.zk_ctx_stream.restype = _vp
+    lib.zk_ceil_log2.restype = _u32
+    lib.zk_fr_partial_me_size.restype = _u32
+    for f in ("zk_fc_in", "zk_fc_out", "zk_fc_com_size"):
+        getattr(lib, f).restype = _u32
+    for f in ("zk_fc_weights", "zk_fc_com", "zk_relu_sign", "zk_relu_mag_bin", "zk_relu_rem_bin"):
+        getattr(lib, f).restype = _vp
+    return lib
+
+
+def _hp(a):
+    return a.ctypes.data_as(_vp)
+
+
+def _fr_host(a, k=None):
+    a = np.ascontiguousarray(a, dtype=np.uint32).reshape(-1, 8)
+    if k is not None and a.shape[0] != k:
+        raise ShapeError(ZK_ERR_SHAPE, "Incompatible dimensions")
+    if a.shape[0] == 0:
+        a = np.zeros((1, 8), dtype=np.uint32)
+    return a
+
+
+class DevArray:
+    """Owning handle of a device buffer of `n` elements of `width` uint32 limbs."""
+
+    def __init__(self, zk, n, width, ptr=None, own=True):
+        self.zk, self.n, self.width, self.own = zk, int(n), int(width), own
+        if ptr is None:
+            p = _vp()
+            zk._chk(zk.lib.zk_malloc(zk.ctx, _sz(max(self.nbytes, 16)), ctypes.byref(p)))
+            ptr = p.value
+        self.ptr = ptr
+
+    @property
+    def nbytes(self):
+        return self.n * self.width * 4
+
+    def download(self):
+        out = np.zeros((self.n, self.width), dtype=np.uint32)
+        if self.n:
+            self.zk._chk(self.zk.lib.zk_memcpy_d2h(self.zk.ctx, _hp(out), _vp(self.ptr), _sz(self.nbytes)))
+        return out
+
+    def view(self, off, n):
+        return DevArray(self.zk, n, self.width, ptr=self.ptr + off * self.width * 4, own=False)
+
+    def free(self):
+        if self.own and self.ptr:
+            self.zk.lib.zk_free(self.zk.ctx, _vp(self.ptr))
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Zk:
+    """One context = one GPU + one HIP stream."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        ctx = _vp()
+        rc = self.lib.zk_ctx_create(int(device), ctypes.byref(ctx))
+        if rc != ZK_OK:
+            raise RuntimeError("zk_ctx_create(device=%d) failed with status %d: no usable MI355X/HIP device "
+                               "(the proving path has no CPU fallback)" % (device, rc))
+        self.ctx = ctx
+        self.device = device
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.zk_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def _chk(self, rc):
+        if rc == ZK_OK:
+            return
+        msg = self.lib.zk_last_error(self.ctx).decode()
+        if rc == ZK_ERR_SHAPE:
+            raise ShapeError(rc, msg)
+        raise ZkError(rc, "zkdl_amd status %d: %s" % (rc, msg))
+
+    # ---- memory
+    def upload(self, a, width=None):
+        a = np.ascontiguousarray(a)
+        if a.dtype != np.uint32:
+            raise TypeError("expected uint32 limbs")
+        width = width or a.shape[-1]
+        a = a.reshape(-1, width)
+        d = DevArray(self, a.shape[0], width)
+        if a.size:
+            self._chk(self.lib.zk_memcpy_h2d(self.ctx, _vp(d.ptr), _hp(a), _sz(a.nbytes)))
+        return d
+
+    def upload_f32(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        d = DevArray(self, a.size, 1)
+        self._chk(self.lib.zk_memcpy_h2d(self.ctx, _vp(d.ptr), _hp(a), _sz(a.nbytes)))
+        return d
+
+    def empty(self, n, width):
+        return DevArray(self, n, width)
+
+    def sync(self):
+        self._chk(self.lib.zk_ctx_sync(self.ctx))
+
+    def seed(self, s):
+        self._chk(self.lib.zk_rng_seed(self.ctx, ctypes.c_uint64(s)))
+
+    def random_vec(self, n):
+        out = np.zeros((max(n, 1), 8), dtype=np.uint32)
+        self._chk(self.lib.zk_random_vec(self.ctx, _u32(n), _hp(out)))
+        return out[:n]
+
+    def fr_random(self, n):
+        d = self.empty(n, 8)
+        self._chk(self.lib.zk_fr_random(self.ctx, _vp(d.ptr), _u32(n)))
+        return d
+
+    def fr_random_int(self, n, bits):
+        d = self.empty(n, 8)
+        self._chk(self.lib.zk_fr_random_int(self.ctx, _vp(d.ptr), _u32(n), _u32(bits)))
+        return d
+
+    # ---- timing / profiling
+    def timer_start(self):
+        self._chk(self.lib.zk_timer_start(self.ctx))
+
+    def timer_stop_ms(self):
+        ms = ctypes.c_float()
+        self._chk(self.lib.zk_timer_stop_ms(self.ctx, ctypes.byref(ms)))
+        return ms.value
+
+    def prof_enable(self, on=True):
+        self._chk(self.lib.zk_prof_enable(self.ctx, int(on)))
+
+    def prof_reset(self):
+        self._chk(self.lib.zk_prof_reset(self.ctx))
+
+    def prof_read(self):
+        cap = 64
+        names = (ctypes.c_char_p * cap)()
+        ms = (ctypes.c_float * cap)()
+        launches = (ctypes.c_uint64 * cap)()
+        nbytes = (ctypes.c_uint64 * cap)()
+        n = ctypes.c_int()
+        self._chk(self.lib.zk_prof_read(self.ctx, names, ms, launches, nbytes, cap, ctypes.byref(n)))
+        return {names[i].decode(): {"ms": ms[i], "launches": int(launches[i]), "bytes": int(nbytes[i])} for i in range(n.value)}
+
+    # ---- Fr tensor
+    def _fr3(self, fn, a, b):
+        if a.n != b.n:
+            raise ShapeError(ZK_ERR_SHAPE, "Incompatible dimensions")
+        out = self.empty(a.n, 8)
+        self._chk(getattr(self.lib, fn)(self.ctx, _vp(a.ptr), _vp(b.ptr), _vp(out.ptr), _u32(a.n)))
+        return out
+
+    def fr_add(self, a, b): return self._fr3("zk_fr_add", a, b)
+    def fr_sub(self, a, b): return self._fr3("zk_fr_sub", a, b)
+    def fr_mul(self, a, b): return self._fr3("zk_fr_mul", a, b)
+
+    def _fr2(self, fn, a):
+        out = self.empty(a.n, 8)
+        self._chk(getattr(self.lib, fn)(self.ctx, _vp(a.ptr), _vp(out.ptr), _u32(a.n)))
+        return out
+
+    def fr_neg(self, a): return self._fr2("zk_fr_neg", a)
+    def fr_mont(self, a): return self._fr2("zk_fr_mont", a)
+    def fr_unmont(self, a): return self._fr2("zk_fr_unmont", a)
+
+    def _frs(self, fn, a, x):
+        x = _fr_host(x, 1)
+        out = self.empty(a.n, 8)
+        self._chk(getattr(self.lib, fn)(self.ctx, _vp(a.ptr), _hp(x), _vp(out.ptr), _u32(a.n)))
+        return out
+
+    def fr_add_scalar(self, a, x): return self._frs("zk_fr_add_scalar", a, x)
+    def fr_sub_scalar(self, a, x): return self._frs("zk_fr_sub_scalar", a, x)
+    def fr_mul_scalar(self, a, x): return self._frs("zk_fr_mul_scalar", a, x)
+
+    def fr_sum(self, a):
+        out = np.zeros(8, dtype=np.uint32)
+        self._chk(self.lib.zk_fr_sum(self.ctx, _vp(a.ptr), _u32(a.n), _hp(out)))
+        return out
+
+    def fr_me(self, t, u):
+        u = np.ascontiguousarray(u, dtype=np.uint32).reshape(-1, 8)
+        out = np.zeros(8, dtype=np.uint32)
+        self._chk(self.lib.zk_fr_me(self.ctx, _vp(t.ptr), _u32(t.n), _hp(_fr_host(u)), _u32(u.shape[0]), _hp(out)))
+        return out
+
+    def fr_partial_me(self, t, u, window):
+        u = np.ascontiguousarray(u, dtype=np.uint32).reshape(-1, 8)
+        n = int(self.lib.zk_fr_partial_me_size(_u32(t.n), _u32(u.shape[0]), _u32(window)))
+        out = self.empty(n, 8)
+        self._chk(self.lib.zk_fr_partial_me(self.ctx, _vp(t.ptr), _u32(t.n), _hp(_fr_host(u)), _u32(u.shape[0]), _u32(window), _vp(out.ptr)))
+        return out
+
+    def fr_split(self, t, window):
+        m = (t.n + 1) // 2
+        o0, o1 = self.empty(m, 8), self.empty(m, 8)
+        self._chk(self.lib.zk_fr_split(self.ctx, _vp(t.ptr), _u32(t.n), _u32(window), _vp(o0.ptr), _vp(o1.ptr)))
+        return o0, o1
+
+    # ---- sumchecks
+    def sumcheck_ip(self, a, b, u):
+        u = np.ascontiguousarray(u, dtype=np.uint32).reshape(-1, 8)
+        if a.n != b.n:
+            raise ShapeError(ZK_ERR_SHAPE, "Incompatible dimensions")
+        k = u.shape[0]
+        out = np.zeros((3 * k + 2, 8), dtype=np.uint32)
+        self._chk(self.lib.zk_sumcheck_ip(self.ctx, _vp(a.ptr), _vp(b.ptr), _u32(a.n), _hp(_fr_host(u)), _u32(k), _hp(out)))
+        return out
+
+    def sumcheck_hadamard(self, a, b, u, v):
+        u = np.ascontiguousarray(u, dtype=np.uint32).reshape(-1, 8)
+        v = np.ascontiguousarray(v, dtype=np.uint32).reshape(-1, 8)
+        if a.n != b.n or u.shape[0] != v.shape[0]:
+            raise ShapeError(ZK_ERR_SHAPE, "Incompatible dimensions")
+        k = u.shape[0]
+        out = np.zeros((3 * k + 2, 8), dtype=np.uint32)
+        self._chk(self.lib.zk_sumcheck_hadamard(self.ctx, _vp(a.ptr), _vp(b.ptr), _u32(a.n), _hp(_fr_host(u)), _hp(_fr_host(v)), _u32(k), _hp(out)))
+        return out
+
+    def sumcheck_binary(self, a, u, v):
+        u = np.ascontiguousarray(u, dtype=np.uint32).reshape(-1, 8)
+        v = np.ascontiguousarray(v, dtype=np.uint32).reshape(-1, 8)
+        if u.shape[0] != v.shape[0]:
+            raise ShapeError(ZK_ERR_SHAPE, "Incompatible dimensions")
+        k = u.shape[0]
+        out = np.zeros((3 * k + 1, 8), dtype=np.uint32)
+        self._chk(self.lib.zk_sumcheck_binary(self.ctx, _vp(a.ptr), _u32(a.n), _hp(_fr_host(u)), _hp(_fr_host(v)), _u32(k), _hp(out)))
+        return out
+
+    # ---- G1 tensor
+    def g1_fill(self, n, g):
+        g = np.ascontiguousarray(g, dtype=np.uint32).reshape(36)
+        out = self.empty(n, 36)
+        self._chk(self.lib.zk_g1_fill(self.ctx, _vp(out.ptr), _u32(n), _hp(g)))
+        return out
+
+    def g1_from_affine(self, a):
+        out = self.empty(a.n, 36)
+        self._chk(self.lib.zk_g1_from_affine(self.ctx, _vp(a.ptr), _vp(out.ptr), _u32(a.n)))
+        return out
+
+    def g1_neg(self, a):
+        out = self.empty(a.n, 36)
+        self._chk(self.lib.zk_g1_neg(self.ctx, _vp(a.ptr), _vp(out.ptr), _u32(a.n)))
+        return out
+
+    def _g3(self, fn, a, b):
+        if a.n != b.n:
+            raise ShapeError(ZK_ERR_SHAPE, "Incompatible dimensions")
+        out = self.empty(a.n, 36)
+        self._chk(getattr(self.lib, fn)(self.ctx, _vp(a.ptr), _vp(b.ptr), _vp(out.ptr), _u32(a.n)))
+        return out
+
+    def g1_add(self, a, b): return self._g3("zk_g1_add", a, b)
+    def g1_sub(self, a, b): return self._g3("zk_g1_sub", a, b)
+    def g1_madd(self, a, b): return self._g3("zk_g1_madd", a, b)
+    def g1_msub(self, a, b): return self._g3("zk_g1_msub", a, b)
+
+    def _gb(self, fn, a, x, w):
+        x = np.ascontiguousarray(x, dtype=np.uint32).reshape(w)
+        out = self.empty(a.n, 36)
+        self._chk(getattr(self.lib, fn)(self.ctx, _vp(a.ptr), _hp(x), _vp(out.ptr), _u32(a.n)))
+        return out
+
+    def g1_add_bcast(self, a, x): return self._gb("zk_g1_add_bcast", a, x, 36)
+    def g1_sub_bcast(self, a, x): return self._gb("zk_g1_sub_bcast", a, x, 36)
+    def g1_madd_bcast(self, a, x): return self._gb("zk_g1_madd_bcast", a, x, 24)
+    def g1_msub_bcast(self, a, x): return self._gb("zk_g1_msub_bcast", a, x, 24)
+
+    def g1_sum(self, a):
+        out = np.zeros(36, dtype=np.uint32)
+        self._chk(self.lib.zk_g1_sum(self.ctx, _vp(a.ptr), _u32(a.n), _hp(out)))
+        return out
+
+    def g1_mul(self, g, s):
+        if g.n != s.n:
+            raise ShapeError(ZK_ERR_SHAPE, "Incompatible dimensions 01")
+        out = self.empty(g.n, 36)
+        self._chk(self.lib.zk_g1_mul(self.ctx, _vp(g.ptr), _vp(s.ptr), _vp(out.ptr), _u32(g.n)))
+        return out
+
+    def g1_mul_bcast(self, g, s):
+        out = self.empty(s.n, 36)
+        self._chk(self.lib.zk_g1_mul_bcast(self.ctx, _vp(g.ptr), _u32(g.n), _vp(s.ptr), _u32(s.n), _vp(out.ptr)))
+        return out
+
+    def g1_me(self, t, u):
+        u = np.ascontiguousarray(u, dtype=np.uint32).reshape(-1, 8)
+        out = np.zeros(36, dtype=np.uint32)
+        self._chk(self.lib.zk_g1_me(self.ctx, _vp(t.ptr), _u32(t.n), _hp(_fr_host(u)), _u32(u.shape[0]), _hp(out)))
+        return out
+
+    def g1_to_affine(self, a):
+        out = self.empty(a.n, 24)
+        inf = DevArray(self, (a.n + 3) // 4 + 1, 1)
+        self._chk(self.lib.zk_g1_to_affine(self.ctx, _vp(a.ptr), _u32(a.n), _vp(out.ptr), _vp(inf.ptr)))
+        flags = inf.download().view(np.uint8).reshape(-1)[:a.n].copy()
+        return out.download(), flags
+
+    # ---- commitment
+    def set_msm_mode(self, mode):
+        self._chk(self.lib.zk_set_msm_mode(self.ctx, int(mode)))
+
+    def set_msm_window(self, bits):
+        self._chk(self.lib.zk_set_msm_window(self.ctx, _u32(bits)))
+
+    def commit(self, gens, t):
+        if gens.n == 0 or t.n % gens.n:
+            raise ShapeError(ZK_ERR_SHAPE, "Incompatible dimensions")
+        out = self.empty(t.n // gens.n, 36)
+        self._chk(self.lib.zk_commit(self.ctx, _vp(gens.ptr), _u32(gens.n), _vp(t.ptr), _u32(t.n), _vp(out.ptr)))
+        return out
+
+    def me_open(self, t, gens, u):
+        u = np.ascontiguousarray(u, dtype=np.uint32).reshape(-1, 8)
+        if t.n != gens.n:
+            raise ShapeError(ZK_ERR_SHAPE, "Incompatible dimensions")
+        k = u.shape[0]
+        proof = np.zeros((3 * k + 1, 36), dtype=np.uint32)
+        ret = np.zeros(8, dtype=np.uint32)
+        self._chk(self.lib.zk_me_open(self.ctx, _vp(t.ptr), _vp(gens.ptr), _u32(t.n), _hp(_fr_host(u)), _u32(k), _hp(proof), _hp(ret)))
+        return ret, proof
+
+    def open(self, gens, t, com, u):
+        u = np.ascontiguousarray(u, dtype=np.uint32).reshape(-1, 8)
+        k = u.shape[0]
+        k_lo = max(k - int(self.lib.zk_ceil_log2(_u32(com.n))), 0)
+        com_eval = np.zeros(36, dtype=np.uint32)
+        proof = np.zeros((3 * k_lo + 1, 36), dtype=np.uint32)
+        ret = np.zeros(8, dtype=np.uint32)
+        self._chk(self.lib.zk_open(self.ctx, _vp(gens.ptr), _u32(gens.n), _vp(t.ptr), _u32(t.n), _vp(com.ptr), _u32(com.n),
+                                   _hp(_fr_host(u)), _u32(k), _hp(com_eval), _hp(proof), _hp(ret)))
+        return ret, com_eval, proof
+
+    # ---- layers
+    def float_to_fr(self, fs_d, rows, rows_p, cols, cols_p):
+        out = self.empty(rows_p * cols_p, 8)
+        self._chk(self.lib.zk_float_to_fr(self.ctx, _vp(fs_d.ptr), _vp(out.ptr), _u32(rows), _u32(rows_p), _u32(cols), _u32(cols_p)))
+        return out
+
+    def ceil_log2(self, x):
+        return int(self.lib.zk_ceil_log2(_u32(x)))
+
+
+class Transcript:
+    def __init__(self, zk):
+        self.zk = zk
+        h = _vp()
+        zk._chk(zk.lib.zk_transcript_create(zk.ctx, ctypes.byref(h)))
+        self.h = h
+
+    def reset(self):
+        self.zk.lib.zk_transcript_reset(self.h)
+
+    def counts(self):
+        a, b = _sz(), _sz()
+        self.zk._chk(self.zk.lib.zk_transcript_counts(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def read(self):
+        nf, ng = self.counts()
+        fr = np.zeros((max(nf, 1), 8), dtype=np.uint32)
+        g1 = np.zeros((max(ng, 1), 36), dtype=np.uint32)
+        self.zk._chk(self.zk.lib.zk_transcript_read(self.h, _hp(fr), _sz(fr.shape[0]), _hp(g1), _sz(g1.shape[0])))
+        return fr[:nf], g1[:ng]
+
+    def read_affine(self):
+        _, ng = self.counts()
+        aff = np.zeros((max(ng, 1), 24), dtype=np.uint32)
+        inf = np.zeros(max(ng, 1), dtype=np.uint8)
+        self.zk._chk(self.zk.lib.zk_transcript_read_affine(self.h, _hp(aff), _hp(inf), _sz(aff.shape[0])))
+        return aff[:ng], inf[:ng]
+
+    def digest(self):
+        out = np.zeros(8, dtype=np.uint32)
+        self.zk._chk(self.zk.lib.zk_transcript_digest(self.h, _hp(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            self.zk.lib.zk_transcript_destroy(self.h)
+            self.h = None
+
+
+class FC:
+    """zkFC (zkfc.cuh:16-33)."""
+
+    def __init__(self, zk, handle):
+        self.zk, self.h = zk, handle
+
+    @classmethod
+    def create(cls, zk, n_in, n_out, weights, gens):
+        h = _vp()
+        zk._chk(zk.lib.zk_fc_create(zk.ctx, _u32(n_in), _u32(n_out), _vp(weights.ptr), _vp(gens.ptr), _u32(gens.n), ctypes.byref(h)))
+        return cls(zk, h)
+
+    @classmethod
+    def from_float(cls, zk, n_in, n_out, w_f32_dev, gens):
+        h = _vp()
+        zk._chk(zk.lib.zk_fc_from_float(zk.ctx, _u32(n_in), _u32(n_out), _vp(w_f32_dev.ptr), _vp(gens.ptr), _u32(gens.n), ctypes.byref(h)))
+        return cls(zk, h)
+
+    @property
+    def n_in(self): return int(self.zk.lib.zk_fc_in(self.h))
+    @property
+    def n_out(self): return int(self.zk.lib.zk_fc_out(self.h))
+    @property
+    def com_size(self): return int(self.zk.lib.zk_fc_com_size(self.h))
+
+    def weights(self):
+        return DevArray(self.zk, self.n_in * self.n_out, 8, ptr=self.zk.lib.zk_fc_weights(self.h), own=False)
+
+    def com(self):
+        return DevArray(self.zk, self.com_size, 36, ptr=self.zk.lib.zk_fc_com(self.h), own=False)
+
+    def forward(self, x):
+        if x.n % self.n_in:
+            raise ShapeError(ZK_ERR_SHAPE, "Incompatible dimensions")
+        z = self.zk.empty(x.n // self.n_in * self.n_out, 8)
+        self.zk._chk(self.zk.lib.zk_fc_forward(self.zk.ctx, self.h, _vp(x.ptr), _u32(x.n), _vp(z.ptr)))
+        return z
+
+    def prove(self, x, z, gens, u_bs, u_in, u_out, tr):
+        zk = self.zk
+        zk._chk(zk.lib.zk_fc_prove(zk.ctx, self.h, _vp(x.ptr), _u32(x.n), _vp(z.ptr), _u32(z.n), _vp(gens.ptr), _u32(gens.n),
+                                   _hp(_fr_host(u_bs)), _hp(_fr_host(u_in)), _hp(_fr_host(u_out)), tr.h))
+
+    def close(self):
+        if self.h:
+            self.zk.lib.zk_fc_destroy(self.h)
+            self.h = None
+
+
+class ReLU:
+    """zkReLU (zkrelu.cuh:10-20)."""
+
+    def __init__(self, zk):
+        self.zk = zk
+        h = _vp()
+        zk._chk(zk.lib.zk_relu_create(zk.ctx, ctypes.byref(h)))
+        self.h = h
+        self.n = 0
+
+    def forward(self, x):
+        z = self.zk.empty(x.n, 8)
+        self.zk._chk(self.zk.lib.zk_relu_forward(self.zk.ctx, self.h, _vp(x.ptr), _u32(x.n), _vp(z.ptr)))
+        self.n = x.n
+        return z
+
+    def aux(self):
+        L = self.zk.lib
+        return (DevArray(self.zk, self.n, 8, ptr=L.zk_relu_sign(self.h), own=False),
+                DevArray(self.zk, self.n * 32, 8, ptr=L.zk_relu_mag_bin(self.h), own=False),
+                DevArray(self.zk, self.n * 16, 8, ptr=L.zk_relu_rem_bin(self.h), own=False))
+
+    def prove(self, x, z, ch, tr):
+        zk = self.zk
+        hs = [_hp(_fr_host(c)) for c in ch]
+        zk._chk(zk.lib.zk_relu_prove(zk.ctx, self.h, _vp(x.ptr), _vp(z.ptr), _u32(x.n), *hs, tr.h))
+
+    def close(self):
+        if self.h:
+            self.zk.lib.zk_relu_destroy(self.h)
+            self.h = None

@@ -1,0 +1,657 @@
+// zkdl_amd/csrc/capi.hip -- the extern "C" surface declared in include/zkdl_amd.h.
+// Thin: argument checks, host<->device staging, then the device-pointer entry points of the
+// other translation units.  Nothing here (or anywhere in the library) falls back to a CPU path:
+// without a usable HIP device zk_ctx_create fails and no other call can be made.
+#include <string.h>
+
+#include <string>
+
+#include "layers.hpp"
+
+using namespace zk;
+
+static_assert(sizeof(zk_fr) == sizeof(Fr) && sizeof(zk_fp) == sizeof(Fp), "POD layout");
+static_assert(sizeof(zk_g1a) == sizeof(G1A) && sizeof(zk_g1j) == sizeof(G1J), "POD layout");
+
+#define CHECK_CTX(ctx) \
+  if (!(ctx)) return ZK_ERR_ARG
+#define CHECK_PTR(ctx, p)                                                                  \
+  if (!(p) || (((uintptr_t)(p)) & 15u)) return (ctx)->fail(ZK_ERR_ARG, "null or misaligned pointer: " #p)
+#define CHECK_HOST(ctx, p) \
+  if (!(p)) return (ctx)->fail(ZK_ERR_ARG, "null host pointer: " #p)
+
+static inline const Fr* F(const zk_fr* p) { return reinterpret_cast<const Fr*>(p); }
+static inline Fr* F(zk_fr* p) { return reinterpret_cast<Fr*>(p); }
+static inline const G1J* J(const zk_g1j* p) { return reinterpret_cast<const G1J*>(p); }
+static inline G1J* J(zk_g1j* p) { return reinterpret_cast<G1J*>(p); }
+static inline const G1A* A(const zk_g1a* p) { return reinterpret_cast<const G1A*>(p); }
+static inline G1A* A(zk_g1a* p) { return reinterpret_cast<G1A*>(p); }
+static inline Fr load_fr(const zk_fr* h) {
+  Fr r;
+  memcpy(&r, h, sizeof(Fr));
+  return r;
+}
+
+void* zk_ctx::stage_put(const void* src, size_t bytes) {
+  size_t need = (bytes + 63) & ~(size_t)63;
+  if (need > stage_cap) return nullptr;
+  if (stage_off + need > stage_cap) {
+    // ring wrapped: everything staged so far must have been consumed
+    if (hipStreamSynchronize(stream) != hipSuccess) return nullptr;
+    stage_off = 0;
+  }
+  void* dst = stage + stage_off;
+  memcpy(dst, src, bytes);
+  stage_off += need;
+  return dst;
+}
+
+void zk_ctx::prof_flush() {
+  if (pending.empty()) return;
+  (void)hipStreamSynchronize(stream);
+  for (auto& p : pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      auto& e = prof[p.name];
+      e.name = p.name;
+      e.ms += ms;
+      e.launches += 1;
+      e.bytes += p.bytes;
+    }
+    event_pool.push_back(p.a);
+    event_pool.push_back(p.b);
+  }
+  pending.clear();
+}
+
+extern "C" {
+
+const char* zk_version(void) { return "zkdl_amd 0.1 (gfx950)"; }
+
+int zk_ctx_create(int device, zk_ctx** out) {
+  if (!out) return ZK_ERR_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return ZK_ERR_DEVICE;
+  if (hipSetDevice(device) != hipSuccess) return ZK_ERR_DEVICE;
+  zk_ctx* ctx = new zk_ctx();
+  ctx->device = device;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&ctx->t0) != hipSuccess ||
+      hipEventCreate(&ctx->t1) != hipSuccess) {
+    delete ctx;
+    return ZK_ERR_DEVICE;
+  }
+  ctx->stage_cap = 4u << 20;
+  if (hipHostMalloc((void**)&ctx->stage, ctx->stage_cap, hipHostMallocDefault) != hipSuccess) {
+    delete ctx;
+    return ZK_ERR_ALLOC;
+  }
+  // keep freed temporaries cached in the stream-ordered pool (288 GB of HBM: never trim)
+  hipMemPool_t pool;
+  if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
+    uint64_t thr = UINT64_MAX;
+    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+  }
+  *out = ctx;
+  return ZK_OK;
+}
+int zk_ctx_destroy(zk_ctx* ctx) {
+  if (!ctx) return ZK_ERR_ARG;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx->prof_flush();
+  for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  (void)hipEventDestroy(ctx->t0);
+  (void)hipEventDestroy(ctx->t1);
+  (void)hipHostFree(ctx->stage);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return ZK_OK;
+}
+int zk_ctx_sync(zk_ctx* ctx) {
+  CHECK_CTX(ctx);
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZK_OK;
+}
+const char* zk_last_error(const zk_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+void* zk_ctx_stream(zk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int zk_malloc(zk_ctx* ctx, size_t bytes, void** out_d) {
+  CHECK_CTX(ctx);
+  CHECK_HOST(ctx, out_d);
+  *out_d = nullptr;
+  if (hipMallocAsync(out_d, bytes ? bytes : 16, ctx->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return ctx->fail(ZK_ERR_ALLOC, "device allocation of " + std::to_string(bytes) + " bytes failed");
+  }
+  return ZK_OK;
+}
+int zk_free(zk_ctx* ctx, void* p) {
+  CHECK_CTX(ctx);
+  if (p) ZK_HIP(ctx, hipFreeAsync(p, ctx->stream));
+  return ZK_OK;
+}
+int zk_memcpy_h2d(zk_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  CHECK_CTX(ctx);
+  if (!bytes) return ZK_OK;
+  // pageable source: make the copy complete before returning so the caller may free src
+  ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZK_OK;
+}
+int zk_memcpy_d2h(zk_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  CHECK_CTX(ctx);
+  if (!bytes) return ZK_OK;
+  ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZK_OK;
+}
+int zk_memcpy_d2d(zk_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  CHECK_CTX(ctx);
+  if (bytes) ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return ZK_OK;
+}
+int zk_memset_zero(zk_ctx* ctx, void* dst, size_t bytes) {
+  CHECK_CTX(ctx);
+  if (bytes) ZK_HIP(ctx, hipMemsetAsync(dst, 0, bytes, ctx->stream));
+  return ZK_OK;
+}
+
+int zk_timer_start(zk_ctx* ctx) {
+  CHECK_CTX(ctx);
+  ZK_HIP(ctx, hipEventRecord(ctx->t0, ctx->stream));
+  return ZK_OK;
+}
+int zk_timer_stop_ms(zk_ctx* ctx, float* ms) {
+  CHECK_CTX(ctx);
+  CHECK_HOST(ctx, ms);
+  ZK_HIP(ctx, hipEventRecord(ctx->t1, ctx->stream));
+  ZK_HIP(ctx, hipEventSynchronize(ctx->t1));
+  ZK_HIP(ctx, hipEventElapsedTime(ms, ctx->t0, ctx->t1));
+  return ZK_OK;
+}
+int zk_prof_enable(zk_ctx* ctx, int on) {
+  CHECK_CTX(ctx);
+  ctx->prof_flush();
+  ctx->prof_on = on != 0;
+  return ZK_OK;
+}
+int zk_prof_reset(zk_ctx* ctx) {
+  CHECK_CTX(ctx);
+  ctx->prof_flush();
+  ctx->prof.clear();
+  return ZK_OK;
+}
+int zk_prof_read(zk_ctx* ctx, const char** names, float* ms, uint64_t* launches, uint64_t* bytes, int cap, int* n) {
+  CHECK_CTX(ctx);
+  ctx->prof_flush();
+  int i = 0;
+  for (auto& kv : ctx->prof) {
+    if (i >= cap) break;
+    if (names) names[i] = kv.second.name;
+    if (ms) ms[i] = (float)kv.second.ms;
+    if (launches) launches[i] = kv.second.launches;
+    if (bytes) bytes[i] = kv.second.bytes;
+    i++;
+  }
+  if (n) *n = i;
+  return ZK_OK;
+}
+
+// ---------------------------------------------------------------- RNG
+int zk_rng_seed(zk_ctx* ctx, uint64_t seed) {
+  CHECK_CTX(ctx);
+  ctx->rng_seed = seed;
+  ctx->rng_draw = 0;
+  return ZK_OK;
+}
+int zk_random_vec(zk_ctx* ctx, uint32_t len, zk_fr* out_h) {
+  CHECK_CTX(ctx);
+  if (len) CHECK_HOST(ctx, out_h);
+  uint64_t draw = ctx->rng_draw++;
+  for (uint32_t i = 0; i < len; i++) {
+    Fr v = rng_fr(ctx->rng_seed, draw, i);
+    memcpy(&out_h[i], &v, sizeof(Fr));
+  }
+  return ZK_OK;
+}
+int zk_fr_random(zk_ctx* ctx, zk_fr* out_d, uint32_t n) {
+  CHECK_CTX(ctx);
+  if (n) CHECK_PTR(ctx, out_d);
+  return fr_random_dev(ctx, F(out_d), n);
+}
+int zk_fr_random_int(zk_ctx* ctx, zk_fr* out_d, uint32_t n, uint32_t num_bits) {
+  CHECK_CTX(ctx);
+  if (n) CHECK_PTR(ctx, out_d);
+  return fr_random_int_dev(ctx, F(out_d), n, num_bits);
+}
+uint32_t zk_ceil_log2(uint32_t num) { return ceil_log2(num); }
+
+// ---------------------------------------------------------------- Fr tensor
+#define FR_BIN(name, op)                                                                        \
+  int name(zk_ctx* ctx, const zk_fr* a, const zk_fr* b, zk_fr* out, uint32_t n) {               \
+    CHECK_CTX(ctx);                                                                             \
+    if (n) { CHECK_PTR(ctx, a); CHECK_PTR(ctx, b); CHECK_PTR(ctx, out); }                       \
+    return fr_binary(ctx, op, F(a), F(b), F(out), n);                                           \
+  }
+FR_BIN(zk_fr_add, OP_ADD)
+FR_BIN(zk_fr_sub, OP_SUB)
+FR_BIN(zk_fr_mul, OP_MUL)
+#define FR_SCALAR(name, op)                                                                     \
+  int name(zk_ctx* ctx, const zk_fr* a, const zk_fr* x_h, zk_fr* out, uint32_t n) {             \
+    CHECK_CTX(ctx);                                                                             \
+    CHECK_HOST(ctx, x_h);                                                                       \
+    if (n) { CHECK_PTR(ctx, a); CHECK_PTR(ctx, out); }                                          \
+    return fr_scalar(ctx, op, F(a), load_fr(x_h), F(out), n);                                   \
+  }
+FR_SCALAR(zk_fr_add_scalar, OP_ADD)
+FR_SCALAR(zk_fr_sub_scalar, OP_SUB)
+FR_SCALAR(zk_fr_mul_scalar, OP_MUL)
+#define FR_UN(name, op)                                                                         \
+  int name(zk_ctx* ctx, const zk_fr* a, zk_fr* out, uint32_t n) {                               \
+    CHECK_CTX(ctx);                                                                             \
+    if (n) { CHECK_PTR(ctx, a); CHECK_PTR(ctx, out); }                                          \
+    return fr_unary(ctx, op, F(a), F(out), n);                                                  \
+  }
+FR_UN(zk_fr_neg, OP_NEG)
+FR_UN(zk_fr_mont, OP_MONT)
+FR_UN(zk_fr_unmont, OP_UNMONT)
+
+int zk_fr_sum(zk_ctx* ctx, const zk_fr* a, uint32_t n, zk_fr* out_h) {
+  CHECK_CTX(ctx);
+  CHECK_HOST(ctx, out_h);
+  if (n) CHECK_PTR(ctx, a);
+  ZK_ALLOC(ctx, dst, Fr, 1);
+  ZK_TRY(fr_sum_dev(ctx, F(a), n, dst.get()));
+  return zk_memcpy_d2h(ctx, out_h, dst.get(), sizeof(Fr));
+}
+int zk_fr_me(zk_ctx* ctx, const zk_fr* t, uint32_t n, const zk_fr* u_h, uint32_t k, zk_fr* out_h) {
+  CHECK_CTX(ctx);
+  CHECK_HOST(ctx, out_h);
+  if (n) CHECK_PTR(ctx, t);
+  if (k) CHECK_HOST(ctx, u_h);
+  DBuf<Fr> u;
+  ZK_TRY(upload_fr(ctx, u, u_h, k));
+  ZK_ALLOC(ctx, dst, Fr, 1);
+  ZK_TRY(fr_me_dev(ctx, F(t), n, u.get(), k, dst.get()));
+  return zk_memcpy_d2h(ctx, out_h, dst.get(), sizeof(Fr));
+}
+uint32_t zk_fr_partial_me_size(uint32_t n, uint32_t k, uint32_t window) { return window ? fr_partial_me_size(n, k, window) : 0; }
+int zk_fr_partial_me(zk_ctx* ctx, const zk_fr* t, uint32_t n, const zk_fr* u_h, uint32_t k, uint32_t window, zk_fr* out) {
+  CHECK_CTX(ctx);
+  if (n) { CHECK_PTR(ctx, t); CHECK_PTR(ctx, out); }
+  if (k) CHECK_HOST(ctx, u_h);
+  DBuf<Fr> u;
+  ZK_TRY(upload_fr(ctx, u, u_h, k));
+  return fr_partial_me_dev(ctx, F(t), n, u.get(), k, window, F(out));
+}
+int zk_fr_split(zk_ctx* ctx, const zk_fr* t, uint32_t n, uint32_t window, zk_fr* o0, zk_fr* o1) {
+  CHECK_CTX(ctx);
+  CHECK_PTR(ctx, t); CHECK_PTR(ctx, o0); CHECK_PTR(ctx, o1);
+  return fr_split_dev(ctx, F(t), n, window, F(o0), F(o1));
+}
+
+// ---------------------------------------------------------------- sumchecks
+int zk_sumcheck_ip(zk_ctx* ctx, const zk_fr* a, const zk_fr* b, uint32_t n, const zk_fr* u_h, uint32_t k, zk_fr* proof_h) {
+  CHECK_CTX(ctx);
+  CHECK_PTR(ctx, a); CHECK_PTR(ctx, b); CHECK_HOST(ctx, proof_h);
+  if (k) CHECK_HOST(ctx, u_h);
+  DBuf<Fr> u;
+  ZK_TRY(upload_fr(ctx, u, u_h, k));
+  ZK_ALLOC(ctx, proof, Fr, 3 * (size_t)k + 2);
+  ZK_TRY(sumcheck_ip_dev(ctx, F(a), F(b), n, u.get(), k, proof.get()));
+  return zk_memcpy_d2h(ctx, proof_h, proof.get(), (3 * (size_t)k + 2) * sizeof(Fr));
+}
+int zk_sumcheck_hadamard(zk_ctx* ctx, const zk_fr* a, const zk_fr* b, uint32_t n, const zk_fr* u_h, const zk_fr* v_h, uint32_t k, zk_fr* proof_h) {
+  CHECK_CTX(ctx);
+  CHECK_PTR(ctx, a); CHECK_PTR(ctx, b); CHECK_HOST(ctx, proof_h);
+  if (k) { CHECK_HOST(ctx, u_h); CHECK_HOST(ctx, v_h); }
+  DBuf<Fr> u, v;
+  ZK_TRY(upload_fr(ctx, u, u_h, k));
+  ZK_TRY(upload_fr(ctx, v, v_h, k));
+  ZK_ALLOC(ctx, proof, Fr, 3 * (size_t)k + 2);
+  ZK_TRY(sumcheck_hp_dev(ctx, F(a), F(b), n, u.get(), v.get(), k, proof.get()));
+  return zk_memcpy_d2h(ctx, proof_h, proof.get(), (3 * (size_t)k + 2) * sizeof(Fr));
+}
+int zk_sumcheck_binary(zk_ctx* ctx, const zk_fr* a, uint32_t n, const zk_fr* u_h, const zk_fr* v_h, uint32_t k, zk_fr* proof_h) {
+  CHECK_CTX(ctx);
+  CHECK_PTR(ctx, a); CHECK_HOST(ctx, proof_h);
+  if (k) { CHECK_HOST(ctx, u_h); CHECK_HOST(ctx, v_h); }
+  DBuf<Fr> u, v;
+  ZK_TRY(upload_fr(ctx, u, u_h, k));
+  ZK_TRY(upload_fr(ctx, v, v_h, k));
+  ZK_ALLOC(ctx, proof, Fr, 3 * (size_t)k + 1);
+  ZK_TRY(sumcheck_bin_dev(ctx, F(a), n, u.get(), v.get(), k, proof.get()));
+  return zk_memcpy_d2h(ctx, proof_h, proof.get(), (3 * (size_t)k + 1) * sizeof(Fr));
+}
+
+// ---------------------------------------------------------------- G1 tensor
+int zk_g1_fill(zk_ctx* ctx, zk_g1j* out, uint32_t n, const zk_g1j* g_h) {
+  CHECK_CTX(ctx);
+  CHECK_HOST(ctx, g_h);
+  if (n) CHECK_PTR(ctx, out);
+  G1J g;
+  memcpy(&g, g_h, sizeof g);
+  return g1_fill_dev(ctx, J(out), n, g);
+}
+int zk_g1a_fill(zk_ctx* ctx, zk_g1a* out, uint32_t n, const zk_g1a* g_h) {
+  CHECK_CTX(ctx);
+  CHECK_HOST(ctx, g_h);
+  if (n) CHECK_PTR(ctx, out);
+  G1A g;
+  memcpy(&g, g_h, sizeof g);
+  return g1a_fill_dev(ctx, A(out), n, g);
+}
+int zk_g1_from_affine(zk_ctx* ctx, const zk_g1a* a, zk_g1j* out, uint32_t n) {
+  CHECK_CTX(ctx);
+  if (n) { CHECK_PTR(ctx, a); CHECK_PTR(ctx, out); }
+  return g1_from_affine_dev(ctx, A(a), J(out), n);
+}
+int zk_g1_neg(zk_ctx* ctx, const zk_g1j* a, zk_g1j* out, uint32_t n) {
+  CHECK_CTX(ctx);
+  if (n) { CHECK_PTR(ctx, a); CHECK_PTR(ctx, out); }
+  return g1_neg_dev(ctx, J(a), J(out), n);
+}
+int zk_g1a_neg(zk_ctx* ctx, const zk_g1a* a, zk_g1a* out, uint32_t n) {
+  CHECK_CTX(ctx);
+  if (n) { CHECK_PTR(ctx, a); CHECK_PTR(ctx, out); }
+  return g1a_neg_dev(ctx, A(a), A(out), n);
+}
+int zk_g1_add(zk_ctx* ctx, const zk_g1j* a, const zk_g1j* b, zk_g1j* out, uint32_t n) {
+  CHECK_CTX(ctx);
+  if (n) { CHECK_PTR(ctx, a); CHECK_PTR(ctx, b); CHECK_PTR(ctx, out); }
+  return g1_addsub_dev(ctx, false, J(a), J(b), J(out), n);
+}
+int zk_g1_sub(zk_ctx* ctx, const zk_g1j* a, const zk_g1j* b, zk_g1j* out, uint32_t n) {
+  CHECK_CTX(ctx);
+  if (n) { CHECK_PTR(ctx, a); CHECK_PTR(ctx, b); CHECK_PTR(ctx, out); }
+  return g1_addsub_dev(ctx, true, J(a), J(b), J(out), n);
+}
+int zk_g1_madd(zk_ctx* ctx, const zk_g1j* a, const zk_g1a* b, zk_g1j* out, uint32_t n) {
+  CHECK_CTX(ctx);
+  if (n) { CHECK_PTR(ctx, a); CHECK_PTR(ctx, b); CHECK_PTR(ctx, out); }
+  return g1_maddsub_dev(ctx, false, J(a), A(b), J(out), n);
+}
+int zk_g1_msub(zk_ctx* ctx, const zk_g1j* a, const zk_g1a* b, zk_g1j* out, uint32_t n) {
+  CHECK_CTX(ctx);
+  if (n) { CHECK_PTR(ctx, a); CHECK_PTR(ctx, b); CHECK_PTR(ctx, out); }
+  return g1_maddsub_dev(ctx, true, J(a), A(b), J(out), n);
+}
+int zk_g1_add_bcast(zk_ctx* ctx, const zk_g1j* a, const zk_g1j* x_h, zk_g1j* out, uint32_t n) {
+  CHECK_CTX(ctx);
+  CHECK_HOST(ctx, x_h);
+  if (n) { CHECK_PTR(ctx, a); CHECK_PTR(ctx, out); }
+  G1J x;
+  memcpy(&x, x_h, sizeof x);
+  return g1_addsub_bcast_dev(ctx, false, J(a), x, J(out), n);
+}
+int zk_g1_sub_bcast(zk_ctx* ctx, const zk_g1j* a, const zk_g1j* x_h, zk_g1j* out, uint32_t n) {
+  CHECK_CTX(ctx);
+  CHECK_HOST(ctx, x_h);
+  if (n) { CHECK_PTR(ctx, a); CHECK_PTR(ctx, out); }
+  G1J x;
+  memcpy(&x, x_h, sizeof x);
+  return g1_addsub_bcast_dev(ctx, true, J(a), x, J(out), n);
+}
+int zk_g1_madd_bcast(zk_ctx* ctx, const zk_g1j* a, const zk_g1a* x_h, zk_g1j* out, uint32_t n) {
+  CHECK_CTX(ctx);
+  CHECK_HOST(ctx, x_h);
+  if (n) { CHECK_PTR(ctx, a); CHECK_PTR(ctx, out); }
+  G1A x;
+  memcpy(&x, x_h, sizeof x);
+  return g1_maddsub_bcast_dev(ctx, false, J(a), x, J(out), n);
+}
+int zk_g1_msub_bcast(zk_ctx* ctx, const zk_g1j* a, const zk_g1a* x_h, zk_g1j* out, uint32_t n) {
+  CHECK_CTX(ctx);
+  CHECK_HOST(ctx, x_h);
+  if (n) { CHECK_PTR(ctx, a); CHECK_PTR(ctx, out); }
+  G1A x;
+  memcpy(&x, x_h, sizeof x);
+  return g1_maddsub_bcast_dev(ctx, true, J(a), x, J(out), n);
+}
+int zk_g1_sum(zk_ctx* ctx, const zk_g1j* a, uint32_t n, zk_g1j* out_h) {
+  CHECK_CTX(ctx);
+  CHECK_HOST(ctx, out_h);
+  if (n) CHECK_PTR(ctx, a);
+  ZK_ALLOC(ctx, dst, G1J, 1);
+  ZK_TRY(g1_sum_dev(ctx, J(a), n, dst.get()));
+  return zk_memcpy_d2h(ctx, out_h, dst.get(), sizeof(G1J));
+}
+int zk_g1_mul(zk_ctx* ctx, const zk_g1j* g, const zk_fr* s, zk_g1j* out, uint32_t n) {
+  CHECK_CTX(ctx);
+  if (n) { CHECK_PTR(ctx, g); CHECK_PTR(ctx, s); CHECK_PTR(ctx, out); }
+  return g1_mul_dev(ctx, J(g), n, F(s), n, J(out));
+}
+int zk_g1_mul_bcast(zk_ctx* ctx, const zk_g1j* g, uint32_t n, const zk_fr* s, uint32_t total, zk_g1j* out) {
+  CHECK_CTX(ctx);
+  if (n == 0 || total % n != 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");  // g1-tensor.cu:448
+  if (total) { CHECK_PTR(ctx, g); CHECK_PTR(ctx, s); CHECK_PTR(ctx, out); }
+  return g1_mul_dev(ctx, J(g), n, F(s), total, J(out));
+}
+int zk_g1_me(zk_ctx* ctx, const zk_g1j* t, uint32_t n, const zk_fr* u_h, uint32_t k, zk_g1j* out_h) {
+  CHECK_CTX(ctx);
+  CHECK_HOST(ctx, out_h);
+  if (n) CHECK_PTR(ctx, t);
+  if (k) CHECK_HOST(ctx, u_h);
+  DBuf<Fr> u;
+  ZK_TRY(upload_fr(ctx, u, u_h, k));
+  ZK_ALLOC(ctx, dst, G1J, 1);
+  ZK_TRY(g1_me_dev(ctx, J(t), n, u.get(), k, dst.get()));
+  return zk_memcpy_d2h(ctx, out_h, dst.get(), sizeof(G1J));
+}
+int zk_g1_to_affine(zk_ctx* ctx, const zk_g1j* a, uint32_t n, zk_g1a* out, uint8_t* inf) {
+  CHECK_CTX(ctx);
+  if (n) { CHECK_PTR(ctx, a); CHECK_PTR(ctx, out); CHECK_HOST(ctx, inf); }
+  return g1_to_affine_dev(ctx, J(a), n, A(out), inf);
+}
+
+// ---------------------------------------------------------------- commitment
+int zk_set_msm_mode(zk_ctx* ctx, int mode) {
+  CHECK_CTX(ctx);
+  if (mode != ZK_MSM_LITERAL && mode != ZK_MSM_PIPPENGER) return ctx->fail(ZK_ERR_ARG, "unknown MSM mode");
+  ctx->msm_mode = mode;
+  return ZK_OK;
+}
+int zk_set_msm_window(zk_ctx* ctx, uint32_t w) {
+  CHECK_CTX(ctx);
+  if (w > 16) return ctx->fail(ZK_ERR_ARG, "MSM window must be 0 (auto) or 1..16 bits");
+  ctx->msm_window = w;
+  return ZK_OK;
+}
+int zk_commit(zk_ctx* ctx, const zk_g1j* gens, uint32_t n, const zk_fr* t, uint32_t tn, zk_g1j* out) {
+  CHECK_CTX(ctx);
+  CHECK_PTR(ctx, gens); CHECK_PTR(ctx, t); CHECK_PTR(ctx, out);
+  return commit_dev(ctx, J(gens), n, F(t), tn, J(out));
+}
+int zk_me_open(zk_ctx* ctx, const zk_fr* t, const zk_g1j* gens, uint32_t n, const zk_fr* u_h, uint32_t k, zk_g1j* proof_h, zk_fr* ret_h) {
+  CHECK_CTX(ctx);
+  CHECK_PTR(ctx, t); CHECK_PTR(ctx, gens); CHECK_HOST(ctx, proof_h); CHECK_HOST(ctx, ret_h);
+  if (k) CHECK_HOST(ctx, u_h);
+  DBuf<Fr> u;
+  ZK_TRY(upload_fr(ctx, u, u_h, k));
+  ZK_ALLOC(ctx, proof, G1J, 3 * (size_t)k + 1);
+  ZK_ALLOC(ctx, ret, Fr, 1);
+  ZK_TRY(me_open_dev(ctx, F(t), J(gens), n, u.get(), k, proof.get(), ret.get()));
+  ZK_TRY(zk_memcpy_d2h(ctx, proof_h, proof.get(), (3 * (size_t)k + 1) * sizeof(G1J)));
+  return zk_memcpy_d2h(ctx, ret_h, ret.get(), sizeof(Fr));
+}
+int zk_open(zk_ctx* ctx, const zk_g1j* gens, uint32_t n, const zk_fr* t, uint32_t tn, const zk_g1j* com, uint32_t m, const zk_fr* u_h, uint32_t k,
+            zk_g1j* com_eval_h, zk_g1j* proof_h, zk_fr* ret_h) {
+  CHECK_CTX(ctx);
+  CHECK_PTR(ctx, gens); CHECK_PTR(ctx, t); CHECK_PTR(ctx, com);
+  CHECK_HOST(ctx, com_eval_h); CHECK_HOST(ctx, proof_h); CHECK_HOST(ctx, ret_h);
+  if (k) CHECK_HOST(ctx, u_h);
+  uint32_t k_hi = ceil_log2(m);
+  if (k_hi > k) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
+  uint32_t k_lo = k - k_hi;
+  DBuf<Fr> u;
+  ZK_TRY(upload_fr(ctx, u, u_h, k));
+  ZK_ALLOC(ctx, proof, G1J, 3 * (size_t)k_lo + 2);
+  ZK_ALLOC(ctx, ret, Fr, 1);
+  ZK_TRY(open_dev(ctx, J(gens), n, F(t), tn, J(com), m, u.get(), k, proof.get(), proof.get() + 1, ret.get()));
+  ZK_TRY(zk_memcpy_d2h(ctx, com_eval_h, proof.get(), sizeof(G1J)));
+  ZK_TRY(zk_memcpy_d2h(ctx, proof_h, proof.get() + 1, (3 * (size_t)k_lo + 1) * sizeof(G1J)));
+  return zk_memcpy_d2h(ctx, ret_h, ret.get(), sizeof(Fr));
+}
+
+// ---------------------------------------------------------------- layers
+int zk_float_to_fr(zk_ctx* ctx, const float* fs, zk_fr* out, uint32_t rows, uint32_t rows_p, uint32_t cols, uint32_t cols_p) {
+  CHECK_CTX(ctx);
+  CHECK_PTR(ctx, out);
+  if (!fs) return ctx->fail(ZK_ERR_ARG, "null pointer: fs_d");
+  return float_to_fr_dev(ctx, fs, F(out), rows, rows_p, cols, cols_p);
+}
+int zk_fc_create(zk_ctx* ctx, uint32_t in, uint32_t out, const zk_fr* w, const zk_g1j* gens, uint32_t n_gens, zk_fc** out_fc) {
+  CHECK_CTX(ctx);
+  CHECK_PTR(ctx, w); CHECK_PTR(ctx, gens); CHECK_HOST(ctx, out_fc);
+  return fc_create(ctx, in, out, F(w), J(gens), n_gens, out_fc);
+}
+int zk_fc_from_float(zk_ctx* ctx, uint32_t in, uint32_t out, const float* w, const zk_g1j* gens, uint32_t n_gens, zk_fc** out_fc) {
+  CHECK_CTX(ctx);
+  CHECK_PTR(ctx, gens); CHECK_HOST(ctx, out_fc);
+  if (!w) return ctx->fail(ZK_ERR_ARG, "null pointer: w_d");
+  if (in == 0 || out == 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
+  uint32_t in_p = 1u << ceil_log2(in), out_p = 1u << ceil_log2(out);  // zkfc.cu:92-93
+  ZK_ALLOC(ctx, wq, Fr, (size_t)in_p * out_p);
+  ZK_TRY(float_to_fr_dev(ctx, w, wq.get(), in, in_p, out, out_p));
+  ZK_TRY(fr_unary(ctx, OP_MONT, wq.get(), wq.get(), in_p * out_p));  // weights.mont(), zkfc.cu:99
+  return fc_create(ctx, in_p, out_p, wq.get(), J(gens), n_gens, out_fc);
+}
+int zk_fc_destroy(zk_fc* fc) {
+  if (!fc) return ZK_ERR_ARG;
+  (void)hipFree(fc->weights);
+  (void)hipFree(fc->com);
+  delete fc;
+  return ZK_OK;
+}
+uint32_t zk_fc_in(const zk_fc* fc) { return fc ? fc->in : 0; }
+uint32_t zk_fc_out(const zk_fc* fc) { return fc ? fc->out : 0; }
+uint32_t zk_fc_com_size(const zk_fc* fc) { return fc ? fc->m : 0; }
+const zk_fr* zk_fc_weights(const zk_fc* fc) { return fc ? reinterpret_cast<const zk_fr*>(fc->weights) : nullptr; }
+const zk_g1j* zk_fc_com(const zk_fc* fc) { return fc ? reinterpret_cast<const zk_g1j*>(fc->com) : nullptr; }
+int zk_fc_load_input(zk_ctx* ctx, uint32_t batch, uint32_t in_dim, const float* x, zk_fr* out) {
+  CHECK_CTX(ctx);
+  CHECK_PTR(ctx, out);
+  if (!x) return ctx->fail(ZK_ERR_ARG, "null pointer: x_d");
+  if (batch == 0 || in_dim == 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
+  return float_to_fr_dev(ctx, x, F(out), batch, 1u << ceil_log2(batch), in_dim, 1u << ceil_log2(in_dim));  // zkfc.cu:108-111
+}
+int zk_fc_forward(zk_ctx* ctx, const zk_fc* fc, const zk_fr* x, uint32_t xn, zk_fr* z) {
+  CHECK_CTX(ctx);
+  if (!fc) return ctx->fail(ZK_ERR_ARG, "null zk_fc");
+  CHECK_PTR(ctx, x); CHECK_PTR(ctx, z);
+  return fc_forward(ctx, fc, F(x), xn, F(z));
+}
+int zk_fc_prove(zk_ctx* ctx, const zk_fc* fc, const zk_fr* x, uint32_t xn, const zk_fr* z, uint32_t zn, const zk_g1j* gens, uint32_t n_gens,
+                const zk_fr* u_bs_h, const zk_fr* u_in_h, const zk_fr* u_out_h, zk_transcript* tr) {
+  CHECK_CTX(ctx);
+  if (!fc || !tr) return ctx->fail(ZK_ERR_ARG, "null zk_fc / zk_transcript");
+  CHECK_PTR(ctx, x); CHECK_PTR(ctx, z); CHECK_PTR(ctx, gens);
+  return fc_prove(ctx, fc, F(x), xn, F(z), zn, J(gens), n_gens, u_bs_h, u_in_h, u_out_h, tr);
+}
+int zk_relu_create(zk_ctx* ctx, zk_relu** out) {
+  CHECK_CTX(ctx);
+  CHECK_HOST(ctx, out);
+  *out = new zk_relu();
+  (*out)->ctx = ctx;
+  return ZK_OK;
+}
+int zk_relu_destroy(zk_relu* relu) {
+  if (!relu) return ZK_ERR_ARG;
+  if (relu->ctx) (void)hipStreamSynchronize(relu->ctx->stream);
+  relu->free_all();
+  delete relu;
+  return ZK_OK;
+}
+int zk_relu_forward(zk_ctx* ctx, zk_relu* relu, const zk_fr* x, uint32_t n, zk_fr* z) {
+  CHECK_CTX(ctx);
+  if (!relu) return ctx->fail(ZK_ERR_ARG, "null zk_relu");
+  if (n) { CHECK_PTR(ctx, x); CHECK_PTR(ctx, z); }
+  return relu_forward(ctx, relu, F(x), n, F(z));
+}
+const zk_fr* zk_relu_sign(const zk_relu* r) { return r ? reinterpret_cast<const zk_fr*>(r->sign) : nullptr; }
+const zk_fr* zk_relu_mag_bin(const zk_relu* r) { return r ? reinterpret_cast<const zk_fr*>(r->mag_bin) : nullptr; }
+const zk_fr* zk_relu_rem_bin(const zk_relu* r) { return r ? reinterpret_cast<const zk_fr*>(r->rem_bin) : nullptr; }
+int zk_relu_prove(zk_ctx* ctx, const zk_relu* relu, const zk_fr* x, const zk_fr* z, uint32_t n, const zk_fr* u_z, const zk_fr* v_z, const zk_fr* u_r,
+                  const zk_fr* v_r, const zk_fr* u_rec, const zk_fr* u_hp, const zk_fr* v_hp, zk_transcript* tr) {
+  CHECK_CTX(ctx);
+  if (!relu || !tr) return ctx->fail(ZK_ERR_ARG, "null zk_relu / zk_transcript");
+  CHECK_PTR(ctx, x); CHECK_PTR(ctx, z);
+  return relu_prove(ctx, relu, F(x), F(z), n, u_z, v_z, u_r, v_r, u_rec, u_hp, v_hp, tr);
+}
+
+// ---------------------------------------------------------------- transcript
+int zk_transcript_create(zk_ctx* ctx, zk_transcript** out) {
+  CHECK_CTX(ctx);
+  CHECK_HOST(ctx, out);
+  *out = new zk_transcript();
+  (*out)->ctx = ctx;
+  return ZK_OK;
+}
+int zk_transcript_destroy(zk_transcript* tr) {
+  if (!tr) return ZK_ERR_ARG;
+  if (tr->fr_d) (void)hipFreeAsync(tr->fr_d, tr->ctx->stream);
+  if (tr->g1_d) (void)hipFreeAsync(tr->g1_d, tr->ctx->stream);
+  delete tr;
+  return ZK_OK;
+}
+int zk_transcript_reset(zk_transcript* tr) {
+  if (!tr) return ZK_ERR_ARG;
+  tr->n_fr = tr->n_g1 = 0;
+  return ZK_OK;
+}
+int zk_transcript_counts(zk_transcript* tr, size_t* n_fr, size_t* n_g1) {
+  if (!tr) return ZK_ERR_ARG;
+  ZK_HIP(tr->ctx, hipStreamSynchronize(tr->ctx->stream));
+  if (n_fr) *n_fr = tr->n_fr;
+  if (n_g1) *n_g1 = tr->n_g1;
+  return ZK_OK;
+}
+int zk_transcript_read(zk_transcript* tr, zk_fr* fr_h, size_t fr_cap, zk_g1j* g1_h, size_t g1_cap) {
+  if (!tr) return ZK_ERR_ARG;
+  zk_ctx* ctx = tr->ctx;
+  if (fr_cap < tr->n_fr || g1_cap < tr->n_g1) return ctx->fail(ZK_ERR_ARG, "transcript buffers too small");
+  if (tr->n_fr) ZK_TRY(zk_memcpy_d2h(ctx, fr_h, tr->fr_d, tr->n_fr * sizeof(Fr)));
+  if (tr->n_g1) ZK_TRY(zk_memcpy_d2h(ctx, g1_h, tr->g1_d, tr->n_g1 * sizeof(G1J)));
+  return zk_ctx_sync(ctx);
+}
+int zk_transcript_read_affine(zk_transcript* tr, zk_g1a* g1_h, uint8_t* inf_h, size_t cap) {
+  if (!tr) return ZK_ERR_ARG;
+  zk_ctx* ctx = tr->ctx;
+  if (cap < tr->n_g1) return ctx->fail(ZK_ERR_ARG, "transcript buffers too small");
+  if (!tr->n_g1) return zk_ctx_sync(ctx);
+  ZK_ALLOC(ctx, aff, G1A, tr->n_g1);
+  ZK_ALLOC(ctx, inf, uint8_t, tr->n_g1);
+  ZK_TRY(g1_to_affine_dev(ctx, tr->g1_d, (uint32_t)tr->n_g1, aff.get(), inf.get()));
+  ZK_TRY(zk_memcpy_d2h(ctx, g1_h, aff.get(), tr->n_g1 * sizeof(G1A)));
+  return zk_memcpy_d2h(ctx, inf_h, inf.get(), tr->n_g1);
+}
+int zk_transcript_digest(zk_transcript* tr, zk_fr* out_h) {
+  if (!tr) return ZK_ERR_ARG;
+  zk_ctx* ctx = tr->ctx;
+  CHECK_HOST(ctx, out_h);
+  std::vector<Fr> frs(tr->n_fr ? tr->n_fr : 1);
+  std::vector<G1A> aff(tr->n_g1 ? tr->n_g1 : 1);
+  std::vector<uint8_t> inf(tr->n_g1 ? tr->n_g1 : 1);
+  if (tr->n_fr) ZK_TRY(zk_memcpy_d2h(ctx, frs.data(), tr->fr_d, tr->n_fr * sizeof(Fr)));
+  ZK_TRY(zk_transcript_read_affine(tr, reinterpret_cast<zk_g1a*>(aff.data()), inf.data(), tr->n_g1));
+  Fr acc = fr_zero();
+  for (size_t i = 0; i < tr->n_fr; i++) acc = fr_add(acc, frs[i]);
+  for (size_t i = 0; i < tr->n_g1; i++) {
+    if (inf[i]) continue;
+    // fold the 2 x 384 affine bits into Fr as 224-bit chunks (each < r)
+    const uint32_t* w = aff[i].x.v;
+    for (int c = 0; c < 4; c++) {
+      const uint32_t* src = (c < 2 ? aff[i].x.v : aff[i].y.v);
+      Fr e = fr_zero();
+      int lo = (c & 1) ? 7 : 0, cnt = (c & 1) ? 5 : 7;
+      for (int j = 0; j < cnt; j++) e.v[j] = src[lo + j];
+      acc = fr_add(acc, e);
+    }
+    (void)w;
+  }
+  memcpy(out_h, &acc, sizeof(Fr));
+  return ZK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,235 @@
+// zkdl_amd/csrc/ctx.hpp -- context, stream-ordered temporaries, launch + profiling plumbing.
+//
+// The reference allocates with cudaMalloc/cudaFree around every operator and calls
+// cudaDeviceSynchronize() after every launch (fr-tensor.cu:92-127).  Here every operation is
+// enqueued on one HIP stream, temporaries come from the stream-ordered pool
+// (hipMallocAsync/hipFreeAsync, release threshold = keep everything), and the host only waits
+// when a value has to cross to it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/zkdl_amd.h"
+#include "field.hpp"
+#include "g1.hpp"
+
+struct zk_prof_entry {
+  const char* name;
+  double ms = 0;
+  uint64_t launches = 0;
+  uint64_t bytes = 0;
+};
+
+struct zk_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string last_error;
+  // RNG (counter-based): element i of draw d of seed s is a pure function of (s, d, i)
+  uint64_t rng_seed = 0;
+  uint64_t rng_draw = 0;
+  // MSM configuration
+  int msm_mode = ZK_MSM_LITERAL;
+  uint32_t msm_window = 0;
+  // timing
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  bool prof_on = false;
+  struct Pending {
+    const char* name;
+    uint64_t bytes;
+    hipEvent_t a, b;
+  };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> event_pool;
+  std::map<std::string, zk_prof_entry> prof;
+  // pinned staging ring for small host->device uploads (challenge vectors, broadcast scalars):
+  // the caller's host buffer may die right after the call returns, the staged copy may not
+  uint8_t* stage = nullptr;
+  size_t stage_cap = 0, stage_off = 0;
+  void* stage_put(const void* src, size_t bytes);  // returns pinned address holding a copy
+
+  int fail(int code, const std::string& msg) {
+    last_error = msg;
+    return code;
+  }
+  hipEvent_t get_event() {
+    if (!event_pool.empty()) {
+      hipEvent_t e = event_pool.back();
+      event_pool.pop_back();
+      return e;
+    }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+  }
+  void prof_flush();
+};
+
+namespace zk {
+
+#define ZK_HIP(ctx, expr)                                                                        \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess)                                                                        \
+      return (ctx)->fail(ZK_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+  } while (0)
+
+#define ZK_TRY(expr)              \
+  do {                            \
+    int _rc = (expr);             \
+    if (_rc != ZK_OK) return _rc; \
+  } while (0)
+
+// Scope that brackets one kernel family launch with HIP events when profiling is enabled.
+struct ProfScope {
+  zk_ctx* ctx;
+  hipEvent_t a = nullptr, b = nullptr;
+  const char* name;
+  uint64_t bytes;
+  ProfScope(zk_ctx* c, const char* n, uint64_t by) : ctx(c), name(n), bytes(by) {
+    if (ctx->prof_on) {
+      a = ctx->get_event();
+      b = ctx->get_event();
+      if (a) (void)hipEventRecord(a, ctx->stream);
+    }
+  }
+  ~ProfScope() {
+    if (a && b) {
+      (void)hipEventRecord(b, ctx->stream);
+      ctx->pending.push_back({name, bytes, a, b});
+    }
+  }
+};
+
+// launch on the context's stream; `bytes` = algorithmic HBM bytes of this launch
+#define ZK_LAUNCH(ctx, name, bytes, kernel, grid, block, shmem, ...)                   \
+  do {                                                                                 \
+    zk::ProfScope _ps((ctx), (name), (uint64_t)(bytes));                               \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);        \
+  } while (0)
+
+// Stream-ordered temporary device buffer.
+template <class T>
+struct DBuf {
+  zk_ctx* ctx = nullptr;
+  T* p = nullptr;
+  size_t n = 0;
+  DBuf() = default;
+  DBuf(zk_ctx* c, size_t count) { alloc(c, count); }
+  DBuf(const DBuf&) = delete;
+  DBuf& operator=(const DBuf&) = delete;
+  DBuf(DBuf&& o) noexcept : ctx(o.ctx), p(o.p), n(o.n) { o.p = nullptr; }
+  DBuf& operator=(DBuf&& o) noexcept {
+    release();
+    ctx = o.ctx; p = o.p; n = o.n;
+    o.p = nullptr;
+    return *this;
+  }
+  bool alloc(zk_ctx* c, size_t count) {
+    release();
+    ctx = c;
+    n = count;
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    if (hipMallocAsync((void**)&p, bytes, c->stream) != hipSuccess) {
+      p = nullptr;
+      (void)hipGetLastError();
+      return false;
+    }
+    return true;
+  }
+  void release() {
+    if (p) (void)hipFreeAsync(p, ctx->stream);
+    p = nullptr;
+  }
+  ~DBuf() { release(); }
+  T* get() const { return p; }
+  explicit operator bool() const { return p != nullptr; }
+};
+
+#define ZK_ALLOC(ctx, buf, T, count)                                                          \
+  zk::DBuf<T> buf;                                                                            \
+  if (!buf.alloc((ctx), (count))) return (ctx)->fail(ZK_ERR_ALLOC, "device allocation failed: " #buf)
+
+inline uint32_t ceil_log2(uint32_t num) {  // proof.cu:13-30 (0 -> 0, 1 -> 0)
+  if (num == 0) return 0;
+  num--;
+  uint32_t r = 0;
+  while (num > 0) {
+    num >>= 1;
+    r++;
+  }
+  return r;
+}
+
+// grid for streaming kernels: enough blocks to fill 256 CUs several times over, grid-stride beyond
+inline uint32_t stream_grid(uint64_t n, uint32_t block = 256, uint32_t max_blocks = 256 * 16) {
+  uint64_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > max_blocks) g = max_blocks;
+  return (uint32_t)g;
+}
+
+// ---- counter-based RNG shared by host (random_vec) and device (FrTensor::random)
+ZK_HD uint64_t mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+ZK_HD Fr rng_fr(uint64_t seed, uint64_t draw, uint64_t idx) {
+  Fr r;
+  uint64_t base = mix64(seed ^ mix64(draw * 0xD1342543DE82EF95ull + 1)) + idx * 4;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    uint64_t w = mix64(base + q);
+    r.v[2 * q] = (uint32_t)w;
+    r.v[2 * q + 1] = (uint32_t)(w >> 32);
+  }
+  r.v[7] %= 1944954707u;  // fr-tensor.cu:346 / proof.cu:9: keeps the value below r
+  return r;
+}
+
+// ---- internal (device-pointer) entry points shared between translation units
+// fr_kernels.hip
+int fr_binary(zk_ctx* ctx, int op, const Fr* a, const Fr* b, Fr* out, uint32_t n);
+int fr_scalar(zk_ctx* ctx, int op, const Fr* a, const Fr& x, Fr* out, uint32_t n);
+int fr_unary(zk_ctx* ctx, int op, const Fr* a, Fr* out, uint32_t n);
+int fr_sum_dev(zk_ctx* ctx, const Fr* a, uint32_t n, Fr* dst_d);
+int fr_me_dev(zk_ctx* ctx, const Fr* t, uint32_t n, const Fr* u_d, uint32_t k, Fr* dst_d);
+int fr_partial_me_dev(zk_ctx* ctx, const Fr* t, uint32_t n, const Fr* u_d, uint32_t k, uint32_t window, Fr* out_d);
+int fr_fold_dev(zk_ctx* ctx, const Fr* in, Fr* out, const Fr* x_d, uint32_t in_size, uint32_t out_size);
+uint32_t fr_partial_me_size(uint32_t n, uint32_t k, uint32_t window);
+int fr_split_dev(zk_ctx* ctx, const Fr* t, uint32_t n, uint32_t window, Fr* o0, Fr* o1);
+int fr_random_dev(zk_ctx* ctx, Fr* out, uint32_t n);
+int fr_random_int_dev(zk_ctx* ctx, Fr* out, uint32_t n, uint32_t num_bits);
+enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_NEG = 3, OP_MONT = 4, OP_UNMONT = 5 };
+// sumcheck.hip
+int sumcheck_ip_dev(zk_ctx* ctx, const Fr* a, const Fr* b, uint32_t n, const Fr* u_d, uint32_t k, Fr* proof_d);
+int sumcheck_hp_dev(zk_ctx* ctx, const Fr* a, const Fr* b, uint32_t n, const Fr* u_d, const Fr* v_d, uint32_t k, Fr* proof_d);
+int sumcheck_bin_dev(zk_ctx* ctx, const Fr* a, uint32_t n, const Fr* u_d, const Fr* v_d, uint32_t k, Fr* proof_d);
+// g1_kernels.hip
+int g1_sum_dev(zk_ctx* ctx, const G1J* a, uint32_t n, G1J* dst_d);
+int g1_me_dev(zk_ctx* ctx, const G1J* t, uint32_t n, const Fr* u_d, uint32_t k, G1J* dst_d);
+int g1_to_affine_dev(zk_ctx* ctx, const G1J* a, uint32_t n, G1A* out, uint8_t* inf);
+// commit.hip
+int commit_dev(zk_ctx* ctx, const G1J* gens, uint32_t n, const Fr* t, uint32_t tn, G1J* out);
+int me_open_dev(zk_ctx* ctx, const Fr* t, const G1J* gens, uint32_t n, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d);
+int open_dev(zk_ctx* ctx, const G1J* gens, uint32_t n, const Fr* t, uint32_t tn, const G1J* com, uint32_t m,
+             const Fr* u_d, uint32_t k, G1J* com_eval_d, G1J* proof_d, Fr* ret_d);
+
+// upload a host challenge vector (k may be 0)
+inline int upload_fr(zk_ctx* ctx, DBuf<Fr>& buf, const zk_fr* h, uint32_t k) {
+  if (!buf.alloc(ctx, k ? k : 1)) return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: challenges");
+  if (k) {
+    void* st = ctx->stage_put(h, (size_t)k * sizeof(Fr));
+    if (!st) return ctx->fail(ZK_ERR_ALLOC, "pinned staging exhausted");
+    ZK_HIP(ctx, hipMemcpyAsync(buf.get(), st, (size_t)k * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+  }
+  return ZK_OK;
+}
+
+}  // namespace zk

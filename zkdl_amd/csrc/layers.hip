@@ -1,0 +1,282 @@
+// zkdl_amd/csrc/layers.hip -- zkFC / zkReLU (forward + prove) and the proof transcript for gfx950
+// (reference: zkfc.cu, zkrelu.cu, demo.cu:23-38,124-138).
+#include "layers.hpp"
+
+#include "dev_util.hpp"
+
+namespace zk {
+
+// ------------------------------------------------------------------ quantiser (zkfc.cu:63-88)
+// v = round-half-away(|x * 2^16|) as uint32; negative -> r - v; zero padding; NOT Montgomery.
+__global__ void __launch_bounds__(256) k_float_to_fr(const float* __restrict__ fs, Fr* __restrict__ frs, uint32_t rows, uint32_t rows_p, uint32_t cols, uint32_t cols_p) {
+  const uint64_t total = (uint64_t)rows_p * cols_p;
+  for (uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; tid < total; tid += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t d0 = (uint32_t)(tid / cols_p), d1 = (uint32_t)(tid - (uint64_t)d0 * cols_p);
+    Fr r = fr_zero();
+    if (d0 < rows && d1 < cols) {
+      float x = fs[(uint64_t)d0 * cols + d1] * 65536.0f;
+      float ax = roundf(fabsf(x));
+      uint32_t v = ax >= 4294967296.0f ? 0xffffffffu : (uint32_t)ax;  // cast is UB in the reference beyond 2^32 (App. D-8): clamp
+      r.v[0] = v;
+      if (copysignf(1.0f, x) < 0.0f) r = fr_sub(fr_zero(), r);
+    }
+    frs[tid] = r;
+  }
+}
+int float_to_fr_dev(zk_ctx* ctx, const float* fs, Fr* out, uint32_t rows, uint32_t rows_p, uint32_t cols, uint32_t cols_p) {
+  if (rows > rows_p || cols > cols_p) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
+  uint64_t total = (uint64_t)rows_p * cols_p;
+  if (total == 0) return ZK_OK;
+  ZK_LAUNCH(ctx, "float_to_fr", 32ull * total + 4ull * rows * cols, k_float_to_fr, dim3(stream_grid(total)), dim3(256), 0, fs, out, rows, rows_p, cols, cols_p);
+  return ZK_OK;
+}
+
+// ------------------------------------------------------------------ field matmul (zkfc.cu:6-47)
+// Z[B x out] = X[B x in] * W[in x out] over Fr (Montgomery product + modular add).  255-bit modular
+// products have no MFMA mapping; this is integer-VALU work.  16x16 output tile per workgroup, the
+// two operand tiles staged through LDS (2 x 8 KiB).
+#define ZK_TILE 16
+__global__ void __launch_bounds__(256) k_fr_matmul(const Fr* __restrict__ A, const Fr* __restrict__ B, Fr* __restrict__ C, uint32_t rowsA, uint32_t colsA, uint32_t colsB) {
+  __shared__ Fr At[ZK_TILE][ZK_TILE];
+  __shared__ Fr Bt[ZK_TILE][ZK_TILE];
+  const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
+  const uint32_t row = blockIdx.y * ZK_TILE + ty, col = blockIdx.x * ZK_TILE + tx;
+  Fr sum = fr_zero();
+  for (uint32_t t0 = 0; t0 < colsA; t0 += ZK_TILE) {
+    At[ty][tx] = (row < rowsA && t0 + tx < colsA) ? A[(uint64_t)row * colsA + t0 + tx] : fr_zero();
+    Bt[ty][tx] = (t0 + ty < colsA && col < colsB) ? B[(uint64_t)(t0 + ty) * colsB + col] : fr_zero();
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t kk = 0; kk < ZK_TILE; kk++) sum = fr_add(sum, fr_mul(At[ty][kk], Bt[kk][tx]));
+    __syncthreads();
+  }
+  if (row < rowsA && col < colsB) C[(uint64_t)row * colsB + col] = sum;
+}
+
+// ------------------------------------------------------------------ ReLU (zkrelu.cu:3-41)
+// Writes the reference's aux tensors (one Fr per bit) AND the same bits packed (32 magnitude bits
+// per element in mag_packed, 16 remainder bits in rem_packed) for the bit-packed prover path.
+__global__ void __launch_bounds__(256) k_relu(const Fr* __restrict__ X, Fr* __restrict__ Z, Fr* __restrict__ sign, Fr* __restrict__ mag_bin, Fr* __restrict__ rem_bin,
+                                               uint32_t* __restrict__ mag_packed, uint16_t* __restrict__ rem_packed, uint8_t* __restrict__ sign_packed, uint32_t n,
+                                               uint32_t* __restrict__ out_of_range) {
+  const Fr one = fr_one(), zero = fr_zero();
+  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
+    Fr x = fr_unmont(X[g]);
+    // positive window: x <= 2^47 - 1 ; negative window: x >= r - 2^47
+    Fr pos_max = fr_zero();
+    pos_max.v[0] = 4294967295u;
+    pos_max.v[1] = 32767u;
+    Fr neg_min;
+    neg_min.v[0] = 1u; neg_min.v[1] = 4294934527u; neg_min.v[2] = 4294859774u; neg_min.v[3] = 1404937218u;
+    neg_min.v[4] = 161601541u; neg_min.v[5] = 859428872u; neg_min.v[6] = 698187080u; neg_min.v[7] = 1944954707u;
+    uint64_t mag = 0;
+    bool positive = false;
+    if (l_gte(pos_max, x)) {
+      positive = true;
+      mag = (uint64_t)x.v[0] | ((uint64_t)x.v[1] << 32);
+    } else if (l_gte(x, neg_min)) {
+      Fr two47 = fr_zero();
+      two47.v[1] = 32768u;
+      Fr y = fr_add(x, two47);
+      mag = (uint64_t)y.v[0] | ((uint64_t)y.v[1] << 32);
+    } else {
+      atomicAdd(out_of_range, 1u);  // undefined in the reference (mag uninitialised); deterministic here: mag = 0, sign = 0
+    }
+    const bool rem_sign = (mag & 32768ull) != 0;
+    const uint32_t rem_mag = (uint32_t)(mag & 32767ull);
+    const int32_t rem = rem_sign ? ((int32_t)rem_mag - (1 << 15)) : (int32_t)rem_mag;
+    const uint32_t mag_rescaled = (uint32_t)((mag - (uint64_t)(int64_t)rem) >> 16);
+    sign[g] = positive ? one : zero;
+    Fr* mb = mag_bin + (uint64_t)g * 32;
+#pragma unroll 4
+    for (uint32_t i = 0; i < 32; i++) mb[i] = ((mag_rescaled >> i) & 1u) ? one : zero;
+    Fr* rb = rem_bin + (uint64_t)g * 16;
+#pragma unroll 4
+    for (uint32_t i = 0; i < 15; i++) rb[i] = ((rem_mag >> i) & 1u) ? one : zero;
+    rb[15] = rem_sign ? one : zero;
+    mag_packed[g] = mag_rescaled;
+    rem_packed[g] = (uint16_t)(rem_mag | (rem_sign ? 0x8000u : 0u));
+    sign_packed[g] = positive ? 1 : 0;
+    Fr mr = fr_zero();
+    mr.v[0] = mag_rescaled;
+    Z[g] = positive ? fr_mont(mr) : zero;  // mont(mag_rescaled) * sign with sign in {ONE, 0}
+  }
+}
+
+}  // namespace zk
+
+using namespace zk;
+
+// ------------------------------------------------------------------ transcript
+int zk_transcript::ensure(size_t add_fr, size_t add_g1) {
+  if (n_fr + add_fr > cap_fr) {
+    size_t nc = cap_fr ? cap_fr : 1024;
+    while (nc < n_fr + add_fr) nc *= 2;
+    Fr* p = nullptr;
+    ZK_HIP(ctx, hipMallocAsync((void**)&p, nc * sizeof(Fr), ctx->stream));
+    if (n_fr) ZK_HIP(ctx, hipMemcpyAsync(p, fr_d, n_fr * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+    if (fr_d) ZK_HIP(ctx, hipFreeAsync(fr_d, ctx->stream));
+    fr_d = p;
+    cap_fr = nc;
+  }
+  if (n_g1 + add_g1 > cap_g1) {
+    size_t nc = cap_g1 ? cap_g1 : 256;
+    while (nc < n_g1 + add_g1) nc *= 2;
+    G1J* p = nullptr;
+    ZK_HIP(ctx, hipMallocAsync((void**)&p, nc * sizeof(G1J), ctx->stream));
+    if (n_g1) ZK_HIP(ctx, hipMemcpyAsync(p, g1_d, n_g1 * sizeof(G1J), hipMemcpyDeviceToDevice, ctx->stream));
+    if (g1_d) ZK_HIP(ctx, hipFreeAsync(g1_d, ctx->stream));
+    g1_d = p;
+    cap_g1 = nc;
+  }
+  return ZK_OK;
+}
+
+// ------------------------------------------------------------------ zkFC
+namespace zk {
+
+int fc_create(zk_ctx* ctx, uint32_t in, uint32_t out, const Fr* weights_d, const G1J* gens_d, uint32_t n_gens, zk_fc** out_fc) {
+  if (in == 0 || out == 0 || n_gens == 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
+  uint64_t wn = (uint64_t)in * out;
+  if (wn > 0xffffffffull || wn % n_gens != 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");  // commitment.cu:31 via zkfc.cu:102
+  zk_fc* fc = new zk_fc();
+  fc->ctx = ctx;
+  fc->in = in;
+  fc->out = out;
+  fc->m = (uint32_t)(wn / n_gens);
+  fc->n_gens = n_gens;
+  if (hipMalloc((void**)&fc->weights, wn * sizeof(Fr)) != hipSuccess || hipMalloc((void**)&fc->com, (size_t)fc->m * sizeof(G1J)) != hipSuccess) {
+    zk_fc_destroy(fc);
+    return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: zkFC");
+  }
+  ZK_HIP(ctx, hipMemcpyAsync(fc->weights, weights_d, wn * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+  int rc = commit_dev(ctx, gens_d, n_gens, fc->weights, (uint32_t)wn, fc->com);
+  if (rc != ZK_OK) {
+    zk_fc_destroy(fc);
+    return rc;
+  }
+  *out_fc = fc;
+  return ZK_OK;
+}
+
+int fc_forward(zk_ctx* ctx, const zk_fc* fc, const Fr* x, uint32_t xn, Fr* z) {
+  if (xn % fc->in != 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");  // zkfc.cu:118
+  uint32_t batch = xn / fc->in;
+  if (batch == 0) return ZK_OK;
+  dim3 grid((fc->out + ZK_TILE - 1) / ZK_TILE, (batch + ZK_TILE - 1) / ZK_TILE);
+  uint64_t bytes = 32ull * ((uint64_t)xn + (uint64_t)fc->in * fc->out + (uint64_t)batch * fc->out);
+  ZK_LAUNCH(ctx, "fc_matmul", bytes, k_fr_matmul, grid, dim3(256), 0, x, (const Fr*)fc->weights, z, batch, fc->in, fc->out);
+  return ZK_OK;
+}
+
+// zkFC::prove, zkfc.cu:128-145
+int fc_prove(zk_ctx* ctx, const zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint32_t zn, const G1J* gens, uint32_t n_gens,
+             const zk_fr* u_bs_h, const zk_fr* u_in_h, const zk_fr* u_out_h, zk_transcript* tr) {
+  if (xn % fc->in != 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions 1");
+  const uint32_t batch = xn / fc->in;
+  const uint32_t k_bs = ceil_log2(batch), k_in = ceil_log2(fc->in), k_out = ceil_log2(fc->out);
+  const uint32_t wn = fc->in * fc->out;
+  // all challenges of this layer in one device array: [u_out | u_in | u_bs]  (so u_out||u_in is contiguous)
+  std::vector<zk_fr> ch(k_out + k_in + k_bs + 1);
+  for (uint32_t i = 0; i < k_out; i++) ch[i] = u_out_h[i];
+  for (uint32_t i = 0; i < k_in; i++) ch[k_out + i] = u_in_h[i];
+  for (uint32_t i = 0; i < k_bs; i++) ch[k_out + k_in + i] = u_bs_h[i];
+  DBuf<Fr> chd;
+  ZK_TRY(upload_fr(ctx, chd, ch.data(), k_out + k_in + k_bs));
+  const Fr* u_out = chd.get();
+  const Fr* u_in = chd.get() + k_out;
+  const Fr* u_bs = chd.get() + k_out + k_in;
+  // u_Z = u_out || u_bs needs its own contiguous copy
+  DBuf<Fr> uz;
+  {
+    std::vector<zk_fr> z_(k_out + k_bs + 1);
+    for (uint32_t i = 0; i < k_out; i++) z_[i] = u_out_h[i];
+    for (uint32_t i = 0; i < k_bs; i++) z_[k_out + i] = u_bs_h[i];
+    ZK_TRY(upload_fr(ctx, uz, z_.data(), k_out + k_bs));
+  }
+  const uint32_t k_lo = ceil_log2(n_gens);
+  ZK_TRY(tr->ensure(3 * k_in + 4, 3 * k_lo + 2));
+
+  // a = X.partial_me(u_bs, in) ; b = W.partial_me(u_out, 1)
+  uint32_t asz = fr_partial_me_size(xn, k_bs, fc->in), bsz = fr_partial_me_size(wn, k_out, 1);
+  if (asz != bsz) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
+  ZK_ALLOC(ctx, a, Fr, asz);
+  ZK_ALLOC(ctx, b, Fr, bsz);
+  ZK_TRY(fr_partial_me_dev(ctx, x, xn, u_bs, k_bs, fc->in, a.get()));
+  ZK_TRY(fr_partial_me_dev(ctx, fc->weights, wn, u_out, k_out, 1, b.get()));
+  ZK_TRY(sumcheck_ip_dev(ctx, a.get(), b.get(), asz, u_in, k_in, tr->fr_d + tr->n_fr));
+  tr->n_fr += 3 * k_in + 2;
+  // Z(u_Z)
+  ZK_TRY(fr_me_dev(ctx, z, zn, uz.get(), k_out + k_bs, tr->fr_d + tr->n_fr));
+  tr->n_fr += 1;
+  // generators.open(weights, com, u_out || u_in)
+  if (k_out + k_in < ceil_log2(fc->m)) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
+  ZK_TRY(open_dev(ctx, gens, n_gens, fc->weights, wn, fc->com, fc->m, u_out, k_out + k_in, tr->g1_d + tr->n_g1, tr->g1_d + tr->n_g1 + 1, tr->fr_d + tr->n_fr));
+  tr->n_fr += 1;
+  tr->n_g1 += 1 + 3 * (k_out + k_in - ceil_log2(fc->m)) + 1;
+  return ZK_OK;
+}
+
+// ------------------------------------------------------------------ zkReLU
+int relu_forward(zk_ctx* ctx, zk_relu* relu, const Fr* x, uint32_t n, Fr* z) {
+  if (n == 0) return ZK_OK;
+  if (relu->cap < n) {  // reset_ptrs, zkrelu.cu:54-63
+    relu->free_all();
+    bool ok = hipMalloc((void**)&relu->sign, (size_t)n * sizeof(Fr)) == hipSuccess && hipMalloc((void**)&relu->mag_bin, (size_t)n * 32 * sizeof(Fr)) == hipSuccess &&
+              hipMalloc((void**)&relu->rem_bin, (size_t)n * 16 * sizeof(Fr)) == hipSuccess && hipMalloc((void**)&relu->mag_packed, (size_t)n * 4) == hipSuccess &&
+              hipMalloc((void**)&relu->rem_packed, (size_t)n * 2) == hipSuccess && hipMalloc((void**)&relu->sign_packed, (size_t)n) == hipSuccess &&
+              hipMalloc((void**)&relu->oor, 4) == hipSuccess;
+    if (!ok) {
+      relu->free_all();
+      return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: zkReLU aux tensors");
+    }
+    relu->cap = n;
+  }
+  relu->n = n;
+  ZK_HIP(ctx, hipMemsetAsync(relu->oor, 0, 4, ctx->stream));
+  ZK_LAUNCH(ctx, "relu_forward", 32ull * 51 * n, k_relu, dim3(stream_grid(n)), dim3(256), 0, x, z, relu->sign, relu->mag_bin, relu->rem_bin, relu->mag_packed,
+            relu->rem_packed, relu->sign_packed, n, relu->oor);
+  uint32_t oor = 0;
+  ZK_HIP(ctx, hipMemcpyAsync(&oor, relu->oor, 4, hipMemcpyDeviceToHost, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (oor) return ctx->fail(ZK_ERR_RANGE, "zkReLU: " + std::to_string(oor) + " input(s) outside the +-2^47 window (undefined in the reference)");
+  return ZK_OK;
+}
+
+// zkReLU::prove, zkrelu.cu:79-100 (Q = 32, R = 16)
+int relu_prove(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const Fr* z, uint32_t n, const zk_fr* u_z_h, const zk_fr* v_z_h, const zk_fr* u_r_h,
+               const zk_fr* v_r_h, const zk_fr* u_rec_h, const zk_fr* u_hp_h, const zk_fr* v_hp_h, zk_transcript* tr) {
+  (void)z;
+  if (relu->n != n || n == 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");  // zkrelu.cu:81
+  if ((uint64_t)n * 32 > 0xffffffffull) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
+  const uint32_t k = ceil_log2(n);
+  const uint32_t lens[7] = {k + 5, k + 5, k + 4, k + 4, k, k, k};
+  const zk_fr* hs[7] = {u_z_h, v_z_h, u_r_h, v_r_h, u_rec_h, u_hp_h, v_hp_h};
+  std::vector<zk_fr> ch;
+  uint32_t offs[7], tot = 0;
+  for (int i = 0; i < 7; i++) {
+    offs[i] = tot;
+    for (uint32_t j = 0; j < lens[i]; j++) ch.push_back(hs[i][j]);
+    tot += lens[i];
+  }
+  ch.push_back(zk_fr{});
+  DBuf<Fr> chd;
+  ZK_TRY(upload_fr(ctx, chd, ch.data(), tot));
+  const Fr* c = chd.get();
+  ZK_TRY(tr->ensure(3 * (k + 5) + 1 + 32 + 3 * (k + 4) + 1 + 16 + 3 * k + 2, 0));
+  Fr* out = tr->fr_d + tr->n_fr;
+  ZK_TRY(sumcheck_bin_dev(ctx, relu->mag_bin, n * 32, c + offs[0], c + offs[1], k + 5, out));
+  out += 3 * (k + 5) + 1;
+  ZK_TRY(fr_partial_me_dev(ctx, relu->mag_bin, n * 32, c + offs[4], k, 32, out));
+  out += 32;
+  ZK_TRY(sumcheck_bin_dev(ctx, relu->rem_bin, n * 16, c + offs[2], c + offs[3], k + 4, out));
+  out += 3 * (k + 4) + 1;
+  ZK_TRY(fr_partial_me_dev(ctx, relu->rem_bin, n * 16, c + offs[4], k, 16, out));
+  out += 16;
+  ZK_TRY(sumcheck_hp_dev(ctx, x, relu->sign, n, c + offs[5], c + offs[6], k, out));
+  out += 3 * k + 2;
+  tr->n_fr = (size_t)(out - tr->fr_d);
+  return ZK_OK;
+}
+
+}  // namespace zk

@@ -1,0 +1,57 @@
+// zkdl_amd/csrc/layers.hpp -- opaque objects behind the C ABI (zk_fc, zk_relu, zk_transcript).
+#pragma once
+#include "ctx.hpp"
+
+struct zk_fc {  // zkFC, zkfc.cuh:16-33: padded weights (Montgomery, [in][out]) + their commitment
+  zk_ctx* ctx = nullptr;
+  uint32_t in = 0, out = 0, m = 0, n_gens = 0;
+  zk::Fr* weights = nullptr;
+  zk::G1J* com = nullptr;
+};
+
+struct zk_relu {  // zkReLU, zkrelu.cuh:10-20: aux tensors of the last forward pass
+  zk_ctx* ctx = nullptr;
+  uint32_t n = 0, cap = 0;
+  zk::Fr *sign = nullptr, *mag_bin = nullptr, *rem_bin = nullptr;
+  uint32_t* mag_packed = nullptr;  // the same bits, 32 per element
+  uint16_t* rem_packed = nullptr;  // 15 remainder bits + sign bit
+  uint8_t* sign_packed = nullptr;
+  uint32_t* oor = nullptr;
+  void free_all() {
+    (void)hipFree(sign); (void)hipFree(mag_bin); (void)hipFree(rem_bin);
+    (void)hipFree(mag_packed); (void)hipFree(rem_packed); (void)hipFree(sign_packed); (void)hipFree(oor);
+    sign = mag_bin = rem_bin = nullptr;
+    mag_packed = nullptr; rem_packed = nullptr; sign_packed = nullptr; oor = nullptr;
+    cap = n = 0;
+  }
+};
+
+struct zk_transcript {  // proof values in the order of SURVEY.md App. A.6, resident on the device
+  zk_ctx* ctx = nullptr;
+  zk::Fr* fr_d = nullptr;
+  zk::G1J* g1_d = nullptr;
+  size_t n_fr = 0, n_g1 = 0, cap_fr = 0, cap_g1 = 0;
+  int ensure(size_t add_fr, size_t add_g1);
+};
+
+namespace zk {
+int float_to_fr_dev(zk_ctx* ctx, const float* fs, Fr* out, uint32_t rows, uint32_t rows_p, uint32_t cols, uint32_t cols_p);
+int fc_create(zk_ctx* ctx, uint32_t in, uint32_t out, const Fr* weights_d, const G1J* gens_d, uint32_t n_gens, zk_fc** out_fc);
+int fc_forward(zk_ctx* ctx, const zk_fc* fc, const Fr* x, uint32_t xn, Fr* z);
+int fc_prove(zk_ctx* ctx, const zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint32_t zn, const G1J* gens, uint32_t n_gens,
+             const zk_fr* u_bs_h, const zk_fr* u_in_h, const zk_fr* u_out_h, zk_transcript* tr);
+int relu_forward(zk_ctx* ctx, zk_relu* relu, const Fr* x, uint32_t n, Fr* z);
+int relu_prove(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const Fr* z, uint32_t n, const zk_fr* u_z_h, const zk_fr* v_z_h, const zk_fr* u_r_h,
+               const zk_fr* v_r_h, const zk_fr* u_rec_h, const zk_fr* u_hp_h, const zk_fr* v_hp_h, zk_transcript* tr);
+// g1_kernels.hip
+int g1_fill_dev(zk_ctx* ctx, G1J* out, uint32_t n, const G1J& g);
+int g1a_fill_dev(zk_ctx* ctx, G1A* out, uint32_t n, const G1A& g);
+int g1_from_affine_dev(zk_ctx* ctx, const G1A* a, G1J* out, uint32_t n);
+int g1_neg_dev(zk_ctx* ctx, const G1J* a, G1J* out, uint32_t n);
+int g1a_neg_dev(zk_ctx* ctx, const G1A* a, G1A* out, uint32_t n);
+int g1_addsub_dev(zk_ctx* ctx, bool sub, const G1J* a, const G1J* b, G1J* out, uint32_t n);
+int g1_maddsub_dev(zk_ctx* ctx, bool sub, const G1J* a, const G1A* b, G1J* out, uint32_t n);
+int g1_addsub_bcast_dev(zk_ctx* ctx, bool sub, const G1J* a, const G1J& x, G1J* out, uint32_t n);
+int g1_maddsub_bcast_dev(zk_ctx* ctx, bool sub, const G1J* a, const G1A& x, G1J* out, uint32_t n);
+int g1_mul_dev(zk_ctx* ctx, const G1J* g, uint32_t n_g, const Fr* s, uint32_t total, G1J* out);
+}  // namespace zk
