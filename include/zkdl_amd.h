@@ -33,6 +33,7 @@ typedef struct { zk_fp x, y; } zk_g1a;          /* G1Affine_t    (fr-tensor.cuh:
 typedef struct { zk_fp x, y, z; } zk_g1j;       /* G1Jacobian_t  (fr-tensor.cuh:15) */
 
 typedef struct zk_ctx zk_ctx;                   /* device + stream + pools + RNG */
+typedef struct zk_gens zk_gens;                 /* Commitment generators (commitment.cuh:8-23) + MSM tables */
 typedef struct zk_fc zk_fc;                     /* zkFC   (zkfc.cuh:16-33)   */
 typedef struct zk_relu zk_relu;                 /* zkReLU (zkrelu.cuh:10-20) */
 typedef struct zk_transcript zk_transcript;     /* proof values the reference computes and drops */
@@ -139,14 +140,24 @@ int zk_g1_to_affine(zk_ctx* ctx, const zk_g1j* a_d, uint32_t n, zk_g1a* out_d, u
 enum { ZK_MSM_LITERAL = 0, ZK_MSM_PIPPENGER = 1 };
 int zk_set_msm_mode(zk_ctx* ctx, int mode);
 int zk_set_msm_window(zk_ctx* ctx, uint32_t window_bits);   /* 0 = automatic */
+/* Commitment object (commitment.cuh:8-23): a generator tensor.  The handle keeps its own copy of the
+ * n Jacobian generators and, for the PIPPENGER back end, lazily builds affine window tables
+ * 2^(c*w) * G_j once (all later MSMs over these generators share them). */
+int zk_gens_create(zk_ctx* ctx, const zk_g1j* gens_d, uint32_t n, zk_gens** out);
+int zk_gens_destroy(zk_gens* g);
+uint32_t zk_gens_size(const zk_gens* g);
+const zk_g1j* zk_gens_points(const zk_gens* g);   /* device pointer to the n Jacobian generators */
 /* Commitment::commit with the INTENDED row semantics:
  * out[row] = sum_j gens[j] * unmont(t[row*n + j]);  tn % n == 0, out holds tn/n points */
-int zk_commit(zk_ctx* ctx, const zk_g1j* gens_d, uint32_t n, const zk_fr* t_d, uint32_t tn, zk_g1j* out_d);
-/* Commitment::me_open: proof_h receives 3k+1 points, *ret_h = t(0) */
-int zk_me_open(zk_ctx* ctx, const zk_fr* t_d, const zk_g1j* gens_d, uint32_t n, const zk_fr* u_h, uint32_t k, zk_g1j* proof_h, zk_fr* ret_h);
+int zk_commit(zk_ctx* ctx, zk_gens* gens, const zk_fr* t_d, uint32_t tn, zk_g1j* out_d);
+/* Commitment::me_open: t holds n = zk_gens_size scalars; proof_h receives 3k+1 points, *ret_h = t(0) */
+int zk_me_open(zk_ctx* ctx, zk_gens* gens, const zk_fr* t_d, const zk_fr* u_h, uint32_t k, zk_g1j* proof_h, zk_fr* ret_h);
 /* Commitment::open: com_eval_h = com(u_hi) (computed and dropped by the reference) */
-int zk_open(zk_ctx* ctx, const zk_g1j* gens_d, uint32_t n, const zk_fr* t_d, uint32_t tn, const zk_g1j* com_d, uint32_t m,
+int zk_open(zk_ctx* ctx, zk_gens* gens, const zk_fr* t_d, uint32_t tn, const zk_g1j* com_d, uint32_t m,
             const zk_fr* u_h, uint32_t k, zk_g1j* com_eval_h, zk_g1j* proof_h, zk_fr* ret_h);
+/* MSM throughput probe for the "G1 MSM Mop/s" metric: q independent MSMs over the handle's n
+ * generators, scalars_d holds q*n canonical Fr values used as raw integers; out_d receives q points */
+int zk_msm_batch(zk_ctx* ctx, zk_gens* gens, const zk_fr* scalars_d, uint32_t q, zk_g1j* out_d);
 
 /* ---------------------------------------------------------------- layers */
 /* float_to_Fr_kernel (zkfc.cu:80-88): quantise rows x cols floats (device) into a zero-padded
@@ -155,9 +166,9 @@ int zk_float_to_fr(zk_ctx* ctx, const float* fs_d, zk_fr* out_d, uint32_t rows, 
 
 /* zkFC (zkfc.cuh:16-33).  weights_d: in*out Montgomery elements, row-major [in][out]; the object
  * keeps its own copy and commits to it with gens (constructor, zkfc.cu:102-104). */
-int zk_fc_create(zk_ctx* ctx, uint32_t in, uint32_t out, const zk_fr* weights_d, const zk_g1j* gens_d, uint32_t n_gens, zk_fc** out_fc);
+int zk_fc_create(zk_ctx* ctx, uint32_t in, uint32_t out, const zk_fr* weights_d, zk_gens* gens, zk_fc** out_fc);
 /* zkFC::from_float_gpu_ptr (zkfc.cu:90-100): pads to powers of two, quantises, mont(), commits */
-int zk_fc_from_float(zk_ctx* ctx, uint32_t in, uint32_t out, const float* w_d, const zk_g1j* gens_d, uint32_t n_gens, zk_fc** out_fc);
+int zk_fc_from_float(zk_ctx* ctx, uint32_t in, uint32_t out, const float* w_d, zk_gens* gens, zk_fc** out_fc);
 int zk_fc_destroy(zk_fc* fc);
 uint32_t zk_fc_in(const zk_fc* fc);
 uint32_t zk_fc_out(const zk_fc* fc);
@@ -171,9 +182,8 @@ int zk_fc_forward(zk_ctx* ctx, const zk_fc* fc, const zk_fr* x_d, uint32_t xn, z
 /* zkFC::prove (zkfc.cu:128-145) with the three challenge vectors made explicit
  * (k_bs = ceilLog2(batch), k_in = ceilLog2(in), k_out = ceilLog2(out)); appends to tr:
  *   Fr: [ip sumcheck 3*k_in+2][Z(u_out||u_bs)][me_open return]   G1: [com(u_hi)][me_open 3*log2(n_gens)+1] */
-int zk_fc_prove(zk_ctx* ctx, const zk_fc* fc, const zk_fr* x_d, uint32_t xn, const zk_fr* z_d, uint32_t zn,
-                const zk_g1j* gens_d, uint32_t n_gens, const zk_fr* u_bs_h, const zk_fr* u_in_h, const zk_fr* u_out_h,
-                zk_transcript* tr);
+int zk_fc_prove(zk_ctx* ctx, zk_fc* fc, const zk_fr* x_d, uint32_t xn, const zk_fr* z_d, uint32_t zn,
+                zk_gens* gens, const zk_fr* u_bs_h, const zk_fr* u_in_h, const zk_fr* u_out_h, zk_transcript* tr);
 
 /* zkReLU (zkrelu.cuh:10-20): owns sign / mag_bin / rem_bin produced by the forward pass */
 int zk_relu_create(zk_ctx* ctx, zk_relu** out_relu);

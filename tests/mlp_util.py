@@ -86,15 +86,13 @@ def prove_mlp_gpu(zk, model, gens_dev=None, timed=False):
     from zkdl_amd.capi import FC, ReLU, Transcript
     sh, L = model["shapes"], len(model["shapes"])
     B_p = model["B_p"]
-    gens = gens_dev or [zk.upload(g) for g in model["gens"]]
+    gens = gens_dev or [zk.gens(zk.upload(g)) for g in model["gens"]]
     fcs = []
     for i, s in enumerate(sh):
         wf = zk.upload_f32(model["W"][i])
         fcs.append(FC.from_float(zk, s["n_in"], s["n_out"], wf, gens[i]))
     xf = zk.upload_f32(model["X"])
-    X = zk.empty(B_p * sh[0]["in_p"], 8)
-    zk._chk(zk.lib.zk_fc_load_input(zk.ctx, model["batch"], model["dims"][0], xf.ptr, X.ptr))
-    X = zk.fr_mont(X)
+    X = zk.fr_mont(zk.fc_load_input(model["batch"], model["dims"][0], xf))
     relus = [ReLU(zk) for _ in range(L - 1)]
     Z, A = [], []
     cur = X

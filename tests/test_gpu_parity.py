@@ -196,7 +196,7 @@ def test_commit_me_open_open_literal(zk, oracle, rng):
     n, m = 8, 4
     gens = rand_points(oracle, rng, n)
     t = small_signed_fr(oracle, rng, n * m)
-    dg, dt = zk.upload(gens), zk.upload(t)
+    dg, dt = zk.gens(zk.upload(gens)), zk.upload(t)
     com = zk.commit(dg, dt)
     want_com = oracle.commit(gens, t)
     assert eq(com.download(), want_com)
@@ -225,7 +225,7 @@ def test_quantiser_matmul_relu(zk, oracle, rng):
     assert eq(Wq.download(), want_Wq)
     gens = rand_points(oracle, rng, 8)
     zk.set_msm_mode(0)
-    fc = FC.from_float(zk, n_in, n_out, zk.upload_f32(W), zk.upload(gens))
+    fc = FC.from_float(zk, n_in, n_out, zk.upload_f32(W), zk.gens(zk.upload(gens)))
     Wm = oracle.fr_mont(want_Wq)
     assert eq(fc.weights().download(), Wm) and (fc.n_in, fc.n_out, fc.com_size) == (8, 8, 8)
     assert eq(fc.com().download(), oracle.commit(gens, Wm))
@@ -270,3 +270,116 @@ def test_mlp_prove_matches_oracle(zk, oracle, dims, batch):
     assert eq(aff_g, aff_o) and eq(inf_g, inf_o)
     _, g1_g = info["tr"].read()
     assert eq(g1_g, g1_o)                      # literal back end keeps the reference's Jacobian limbs
+
+
+# ------------------------------------------------------------------ Pippenger / flattened back end (affine-canonical)
+def affine_of(oracle, pts):
+    return oracle.g1_to_affine(np.asarray(pts).reshape(-1, 36))
+
+
+@pytest.mark.parametrize("n,m,kind", [(8, 4, "small"), (64, 16, "small"), (32, 8, "full"), (16, 5, "mixed"), (128, 3, "small")])
+def test_commit_pippenger_affine_parity(zk, oracle, rng, n, m, kind):
+    from zkdl_amd.capi import MSM_PIPPENGER
+    zk.set_msm_mode(MSM_PIPPENGER)
+    gens = rand_points(oracle, rng, n)
+    if kind == "small":
+        t = small_signed_fr(oracle, rng, n * m)
+    elif kind == "full":
+        t = rand_fr(rng, n * m)
+    else:
+        t = small_signed_fr(oracle, rng, n * m)
+        t[:n] = 0                                 # an all-zero (padded) row commits to infinity
+        t[n:n + 3] = rand_fr(rng, 3)              # a few full-width scalars force the wide path
+        t[2 * n] = oracle.fr_mont(oracle.fr_neg(np.eye(1, 8, 0, dtype=np.uint32)))[0]   # r - 1
+    got = zk.commit(zk.gens(zk.upload(gens)), zk.upload(t)).download()
+    want = oracle.commit(gens, t)
+    ga, gi = affine_of(oracle, got)
+    wa, wi = affine_of(oracle, want)
+    assert eq(ga, wa) and eq(gi, wi)
+    if kind == "mixed":
+        assert gi[0] == 1
+    # canonical output form: Z = ONE (or the canonical infinity)
+    one = oracle.constants()["fp_one"]
+    for p, inf in zip(got, gi):
+        assert eq(p[24:36], np.zeros(12, np.uint32) if inf else one)
+
+
+@pytest.mark.parametrize("n,k", [(2, 1), (8, 3), (64, 6)])
+def test_me_open_flattened_affine_parity(zk, oracle, rng, n, k):
+    from zkdl_amd.capi import MSM_PIPPENGER
+    zk.set_msm_mode(MSM_PIPPENGER)
+    gens = rand_points(oracle, rng, n)
+    t, u = rand_fr(rng, n), rand_fr(rng, k)
+    ret, proof = zk.me_open(zk.upload(t), zk.gens(zk.upload(gens)), u)
+    wret, wproof = oracle.me_open(t, gens, u)
+    assert eq(ret, wret)
+    ga, gi = affine_of(oracle, proof)
+    wa, wi = affine_of(oracle, wproof)
+    assert eq(ga, wa) and eq(gi, wi)
+
+
+def test_open_and_msm_batch_pippenger(zk, oracle, rng):
+    from zkdl_amd.capi import MSM_PIPPENGER
+    import bigint_model as bm
+    zk.set_msm_mode(MSM_PIPPENGER)
+    n, m = 16, 8
+    gens = rand_points(oracle, rng, n)
+    t = small_signed_fr(oracle, rng, n * m)
+    t[3 * n:4 * n] = 0                            # infinite commitment point inside com(u)
+    dg = zk.gens(zk.upload(gens))
+    com = zk.commit(dg, zk.upload(t))
+    want_com = oracle.commit(gens, t)
+    u = rand_fr(rng, 7)
+    ret, ce, proof = zk.open(dg, zk.upload(t), com, u)
+    wret, wce, wproof = oracle.open(gens, t, want_com, u)
+    assert eq(ret, wret)
+    for g, w in ((ce, wce), (proof, wproof)):
+        ga, gi = affine_of(oracle, g)
+        wa, wi = affine_of(oracle, w)
+        assert eq(ga, wa) and eq(gi, wi)
+    # raw-scalar MSM probe against the big-integer model
+    q = 3
+    s = rand_fr(rng, q * n)
+    s[0] = 0
+    s[1] = oracle.constants()["fr_p"] - np.eye(1, 8, 0, dtype=np.uint32)[0]      # r - 1
+    out = zk.msm_batch(dg, zk.upload(s)).download()
+    gi_ = [bm.jac_to_affine_int(g) for g in gens]
+    for row in range(q):
+        want = None
+        for j in range(n):
+            want = bm.g1_add(want, bm.g1_mul(gi_[j], bm.limbs_to_int(s[row * n + j])))
+        assert bm.jac_to_affine_int(out[row]) == want
+
+
+@pytest.mark.parametrize("window", [0, 4, 9])
+def test_msm_window_sweep_gives_same_points(zk, oracle, rng, window):
+    from zkdl_amd.capi import MSM_PIPPENGER
+    zk.set_msm_mode(MSM_PIPPENGER)
+    zk.set_msm_window(window)
+    try:
+        n, m = 32, 4
+        gens = rand_points(oracle, rng, n)
+        t = rand_fr(rng, n * m)
+        got = zk.commit(zk.gens(zk.upload(gens)), zk.upload(t)).download()
+        ga, gi = affine_of(oracle, got)
+        wa, wi = affine_of(oracle, oracle.commit(gens, t))
+        assert eq(ga, wa) and eq(gi, wi)
+    finally:
+        zk.set_msm_window(0)
+
+
+@pytest.mark.parametrize("dims,batch", [([6, 5, 4], 3), ([16, 32, 8], 4)])
+def test_mlp_prove_pippenger_matches_oracle(zk, oracle, dims, batch):
+    from mlp_util import prove_mlp_gpu, prove_mlp_oracle, synth_mlp
+    from zkdl_amd.capi import MSM_PIPPENGER
+    zk.set_msm_mode(MSM_PIPPENGER)
+    model = synth_mlp(oracle, dims, batch, seed=12)
+    fr_o, g1_o = prove_mlp_oracle(oracle, model)
+    fr_g, aff_g, inf_g, info = prove_mlp_gpu(zk, model)
+    assert eq(fr_g, fr_o)
+    aff_o, inf_o = oracle.g1_to_affine(g1_o)
+    assert eq(aff_g, aff_o) and eq(inf_g, inf_o)
+    for a, b in zip(info["coms"], model["_oracle"]["coms"]):
+        ga, gi = affine_of(oracle, a)
+        wa, wi = affine_of(oracle, b)
+        assert eq(ga, wa) and eq(gi, wi)

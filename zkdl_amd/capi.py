@@ -29,7 +29,7 @@ zk_fr_add_scalar zk_fr_sub_scalar zk_fr_mul_scalar zk_fr_mont zk_fr_unmont zk_fr
 zk_fr_partial_me zk_fr_split zk_sumcheck_ip zk_sumcheck_hadamard zk_sumcheck_binary zk_g1_fill zk_g1a_fill
 zk_g1_from_affine zk_g1_neg zk_g1a_neg zk_g1_add zk_g1_sub zk_g1_madd zk_g1_msub zk_g1_add_bcast zk_g1_sub_bcast
 zk_g1_madd_bcast zk_g1_msub_bcast zk_g1_sum zk_g1_mul zk_g1_mul_bcast zk_g1_me zk_g1_to_affine zk_set_msm_mode
-zk_set_msm_window zk_commit zk_me_open zk_open zk_float_to_fr zk_fc_create zk_fc_from_float zk_fc_destroy zk_fc_in
+zk_set_msm_window zk_gens_create zk_gens_destroy zk_gens_size zk_gens_points zk_commit zk_me_open zk_open zk_msm_batch zk_float_to_fr zk_fc_create zk_fc_from_float zk_fc_destroy zk_fc_in
 zk_fc_out zk_fc_com_size zk_fc_weights zk_fc_com zk_fc_load_input zk_fc_forward zk_fc_prove zk_relu_create
 zk_relu_destroy zk_relu_forward zk_relu_sign zk_relu_mag_bin zk_relu_rem_bin zk_relu_prove zk_transcript_create
 zk_transcript_destroy zk_transcript_reset zk_transcript_counts zk_transcript_read zk_transcript_read_affine
@@ -46,20 +46,45 @@ class ShapeError(ZkError, ValueError):
     """The reference's std::runtime_error("Incompatible dimensions ...")."""
 
 
+_CTYPE = {"int": ctypes.c_int, "uint32_t": _u32, "uint64_t": ctypes.c_uint64, "size_t": _sz, "float": ctypes.c_float}
+
+
+def _header_prototypes():
+    """(name, restype, argtypes) for every function include/zkdl_amd.h declares: pointers of any
+    kind -> c_void_p, so a Python int can never be truncated to a 32-bit C int on its way in."""
+    import re
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "zkdl_amd.h")
+    text = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)
+    protos = []
+    for ret, name, args in re.findall(r"([A-Za-z_][\w \*]*?)\b(zk_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text):
+        ret = ret.strip()
+        if "*" in ret:
+            restype = ctypes.c_char_p if "char" in ret else _vp
+        else:
+            restype = _CTYPE.get(ret.replace("const", "").strip(), ctypes.c_int)
+        argtypes = []
+        args = args.strip()
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(_vp)
+                else:
+                    base = a.replace("const", "").split()[0]
+                    argtypes.append(_CTYPE[base])
+        protos.append((name, restype, argtypes))
+    return protos
+
+
 def load_library():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libzkdl_amd.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                            "there is no CPU fallback for the proving path")
     lib = ctypes.CDLL(LIB_PATH)
-    lib.zk_last_error.restype = ctypes.c_char_p
-    lib.zk_version.restype = ctypes.c_char_p
-    lib.zk_ctx_stream.restype = _vp
-    lib.zk_ceil_log2.restype = _u32
-    lib.zk_fr_partial_me_size.restype = _u32
-    for f in ("zk_fc_in", "zk_fc_out", "zk_fc_com_size"):
-        getattr(lib, f).restype = _u32
-    for f in ("zk_fc_weights", "zk_fc_com", "zk_relu_sign", "zk_relu_mag_bin", "zk_relu_rem_bin"):
-        getattr(lib, f).restype = _vp
+    for name, restype, argtypes in _header_prototypes():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
     return lib
 
 
@@ -367,11 +392,15 @@ class Zk:
     def set_msm_window(self, bits):
         self._chk(self.lib.zk_set_msm_window(self.ctx, _u32(bits)))
 
+    def gens(self, points):
+        """Commitment generators handle (commitment.cuh:8-23) from a DevArray of Jacobian points."""
+        return Gens(self, points)
+
     def commit(self, gens, t):
         if gens.n == 0 or t.n % gens.n:
             raise ShapeError(ZK_ERR_SHAPE, "Incompatible dimensions")
         out = self.empty(t.n // gens.n, 36)
-        self._chk(self.lib.zk_commit(self.ctx, _vp(gens.ptr), _u32(gens.n), _vp(t.ptr), _u32(t.n), _vp(out.ptr)))
+        self._chk(self.lib.zk_commit(self.ctx, gens.h, _vp(t.ptr), _u32(t.n), _vp(out.ptr)))
         return out
 
     def me_open(self, t, gens, u):
@@ -381,7 +410,7 @@ class Zk:
         k = u.shape[0]
         proof = np.zeros((3 * k + 1, 36), dtype=np.uint32)
         ret = np.zeros(8, dtype=np.uint32)
-        self._chk(self.lib.zk_me_open(self.ctx, _vp(t.ptr), _vp(gens.ptr), _u32(t.n), _hp(_fr_host(u)), _u32(k), _hp(proof), _hp(ret)))
+        self._chk(self.lib.zk_me_open(self.ctx, gens.h, _vp(t.ptr), _hp(_fr_host(u)), _u32(k), _hp(proof), _hp(ret)))
         return ret, proof
 
     def open(self, gens, t, com, u):
@@ -391,9 +420,18 @@ class Zk:
         com_eval = np.zeros(36, dtype=np.uint32)
         proof = np.zeros((3 * k_lo + 1, 36), dtype=np.uint32)
         ret = np.zeros(8, dtype=np.uint32)
-        self._chk(self.lib.zk_open(self.ctx, _vp(gens.ptr), _u32(gens.n), _vp(t.ptr), _u32(t.n), _vp(com.ptr), _u32(com.n),
+        self._chk(self.lib.zk_open(self.ctx, gens.h, _vp(t.ptr), _u32(t.n), _vp(com.ptr), _u32(com.n),
                                    _hp(_fr_host(u)), _u32(k), _hp(com_eval), _hp(proof), _hp(ret)))
         return ret, com_eval, proof
+
+    def msm_batch(self, gens, scalars):
+        """q = scalars.n / gens.n independent MSMs over the handle's generators (raw canonical scalars)."""
+        if gens.n == 0 or scalars.n % gens.n:
+            raise ShapeError(ZK_ERR_SHAPE, "Incompatible dimensions")
+        q = scalars.n // gens.n
+        out = self.empty(q, 36)
+        self._chk(self.lib.zk_msm_batch(self.ctx, gens.h, _vp(scalars.ptr), _u32(q), _vp(out.ptr)))
+        return out
 
     # ---- layers
     def float_to_fr(self, fs_d, rows, rows_p, cols, cols_p):
@@ -403,6 +441,32 @@ class Zk:
 
     def ceil_log2(self, x):
         return int(self.lib.zk_ceil_log2(_u32(x)))
+
+    def fc_load_input(self, batch, in_dim, x_f32_dev):
+        """zkFC::load_float_gpu_input (zkfc.cu:106-115): quantise + zero-pad to powers of two."""
+        b_p, in_p = 1 << self.ceil_log2(batch), 1 << self.ceil_log2(in_dim)
+        out = self.empty(b_p * in_p, 8)
+        self._chk(self.lib.zk_fc_load_input(self.ctx, _u32(batch), _u32(in_dim), _vp(x_f32_dev.ptr), _vp(out.ptr)))
+        return out
+
+
+class Gens:
+    """Commitment object (commitment.cuh:8-23): generator tensor + lazily built MSM window tables."""
+
+    def __init__(self, zk, points):
+        self.zk = zk
+        h = _vp()
+        zk._chk(zk.lib.zk_gens_create(zk.ctx, _vp(points.ptr), _u32(points.n), ctypes.byref(h)))
+        self.h = h
+        self.n = points.n
+
+    def points(self):
+        return DevArray(self.zk, self.n, 36, ptr=self.zk.lib.zk_gens_points(self.h), own=False)
+
+    def close(self):
+        if self.h:
+            self.zk.lib.zk_gens_destroy(self.h)
+            self.h = None
 
 
 class Transcript:
@@ -454,13 +518,13 @@ class FC:
     @classmethod
     def create(cls, zk, n_in, n_out, weights, gens):
         h = _vp()
-        zk._chk(zk.lib.zk_fc_create(zk.ctx, _u32(n_in), _u32(n_out), _vp(weights.ptr), _vp(gens.ptr), _u32(gens.n), ctypes.byref(h)))
+        zk._chk(zk.lib.zk_fc_create(zk.ctx, _u32(n_in), _u32(n_out), _vp(weights.ptr), gens.h, ctypes.byref(h)))
         return cls(zk, h)
 
     @classmethod
     def from_float(cls, zk, n_in, n_out, w_f32_dev, gens):
         h = _vp()
-        zk._chk(zk.lib.zk_fc_from_float(zk.ctx, _u32(n_in), _u32(n_out), _vp(w_f32_dev.ptr), _vp(gens.ptr), _u32(gens.n), ctypes.byref(h)))
+        zk._chk(zk.lib.zk_fc_from_float(zk.ctx, _u32(n_in), _u32(n_out), _vp(w_f32_dev.ptr), gens.h, ctypes.byref(h)))
         return cls(zk, h)
 
     @property
@@ -485,7 +549,7 @@ class FC:
 
     def prove(self, x, z, gens, u_bs, u_in, u_out, tr):
         zk = self.zk
-        zk._chk(zk.lib.zk_fc_prove(zk.ctx, self.h, _vp(x.ptr), _u32(x.n), _vp(z.ptr), _u32(z.n), _vp(gens.ptr), _u32(gens.n),
+        zk._chk(zk.lib.zk_fc_prove(zk.ctx, self.h, _vp(x.ptr), _u32(x.n), _vp(z.ptr), _u32(z.n), gens.h,
                                    _hp(_fr_host(u_bs)), _hp(_fr_host(u_in)), _hp(_fr_host(u_out)), tr.h))
 
     def close(self):

@@ -458,40 +458,65 @@ int zk_set_msm_window(zk_ctx* ctx, uint32_t w) {
   ctx->msm_window = w;
   return ZK_OK;
 }
-int zk_commit(zk_ctx* ctx, const zk_g1j* gens, uint32_t n, const zk_fr* t, uint32_t tn, zk_g1j* out) {
+int zk_gens_create(zk_ctx* ctx, const zk_g1j* gens, uint32_t n, zk_gens** out) {
   CHECK_CTX(ctx);
-  CHECK_PTR(ctx, gens); CHECK_PTR(ctx, t); CHECK_PTR(ctx, out);
-  return commit_dev(ctx, J(gens), n, F(t), tn, J(out));
+  CHECK_PTR(ctx, gens); CHECK_HOST(ctx, out);
+  return gens_create(ctx, J(gens), n, true, out);
 }
-int zk_me_open(zk_ctx* ctx, const zk_fr* t, const zk_g1j* gens, uint32_t n, const zk_fr* u_h, uint32_t k, zk_g1j* proof_h, zk_fr* ret_h) {
+int zk_gens_destroy(zk_gens* g) {
+  if (!g) return ZK_ERR_ARG;
+  gens_destroy(g);
+  return ZK_OK;
+}
+uint32_t zk_gens_size(const zk_gens* g) { return g ? g->n : 0; }
+const zk_g1j* zk_gens_points(const zk_gens* g) { return g ? reinterpret_cast<const zk_g1j*>(g->pts) : nullptr; }
+int zk_commit(zk_ctx* ctx, zk_gens* gens, const zk_fr* t, uint32_t tn, zk_g1j* out) {
   CHECK_CTX(ctx);
-  CHECK_PTR(ctx, t); CHECK_PTR(ctx, gens); CHECK_HOST(ctx, proof_h); CHECK_HOST(ctx, ret_h);
+  if (!gens) return ctx->fail(ZK_ERR_ARG, "null zk_gens");
+  CHECK_PTR(ctx, t); CHECK_PTR(ctx, out);
+  return commit_dev(ctx, gens, F(t), tn, J(out));
+}
+int zk_me_open(zk_ctx* ctx, zk_gens* gens, const zk_fr* t, const zk_fr* u_h, uint32_t k, zk_g1j* proof_h, zk_fr* ret_h) {
+  CHECK_CTX(ctx);
+  if (!gens) return ctx->fail(ZK_ERR_ARG, "null zk_gens");
+  CHECK_PTR(ctx, t); CHECK_HOST(ctx, proof_h); CHECK_HOST(ctx, ret_h);
   if (k) CHECK_HOST(ctx, u_h);
   DBuf<Fr> u;
   ZK_TRY(upload_fr(ctx, u, u_h, k));
   ZK_ALLOC(ctx, proof, G1J, 3 * (size_t)k + 1);
   ZK_ALLOC(ctx, ret, Fr, 1);
-  ZK_TRY(me_open_dev(ctx, F(t), J(gens), n, u.get(), k, proof.get(), ret.get()));
+  ZK_TRY(me_open_dev(ctx, gens, F(t), u.get(), k, proof.get(), ret.get()));
   ZK_TRY(zk_memcpy_d2h(ctx, proof_h, proof.get(), (3 * (size_t)k + 1) * sizeof(G1J)));
   return zk_memcpy_d2h(ctx, ret_h, ret.get(), sizeof(Fr));
 }
-int zk_open(zk_ctx* ctx, const zk_g1j* gens, uint32_t n, const zk_fr* t, uint32_t tn, const zk_g1j* com, uint32_t m, const zk_fr* u_h, uint32_t k,
-            zk_g1j* com_eval_h, zk_g1j* proof_h, zk_fr* ret_h) {
+int zk_open(zk_ctx* ctx, zk_gens* gens, const zk_fr* t, uint32_t tn, const zk_g1j* com, uint32_t m, const zk_fr* u_h, uint32_t k, zk_g1j* com_eval_h,
+            zk_g1j* proof_h, zk_fr* ret_h) {
   CHECK_CTX(ctx);
-  CHECK_PTR(ctx, gens); CHECK_PTR(ctx, t); CHECK_PTR(ctx, com);
+  if (!gens) return ctx->fail(ZK_ERR_ARG, "null zk_gens");
+  CHECK_PTR(ctx, t); CHECK_PTR(ctx, com);
   CHECK_HOST(ctx, com_eval_h); CHECK_HOST(ctx, proof_h); CHECK_HOST(ctx, ret_h);
   if (k) CHECK_HOST(ctx, u_h);
   uint32_t k_hi = ceil_log2(m);
-  if (k_hi > k) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
+  if (m == 0 || k_hi > k) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   uint32_t k_lo = k - k_hi;
   DBuf<Fr> u;
   ZK_TRY(upload_fr(ctx, u, u_h, k));
   ZK_ALLOC(ctx, proof, G1J, 3 * (size_t)k_lo + 2);
   ZK_ALLOC(ctx, ret, Fr, 1);
-  ZK_TRY(open_dev(ctx, J(gens), n, F(t), tn, J(com), m, u.get(), k, proof.get(), proof.get() + 1, ret.get()));
-  ZK_TRY(zk_memcpy_d2h(ctx, com_eval_h, proof.get(), sizeof(G1J)));
-  ZK_TRY(zk_memcpy_d2h(ctx, proof_h, proof.get() + 1, (3 * (size_t)k_lo + 1) * sizeof(G1J)));
-  return zk_memcpy_d2h(ctx, ret_h, ret.get(), sizeof(Fr));
+  zk_gens* cg = nullptr;  // ad-hoc handle over the caller's commitment tensor (zkFC keeps a persistent one)
+  ZK_TRY(gens_create(ctx, J(com), m, true, &cg));
+  int rc = open_dev(ctx, gens, F(t), tn, cg, u.get(), k, proof.get(), proof.get() + 1, ret.get());
+  if (rc == ZK_OK) rc = zk_memcpy_d2h(ctx, com_eval_h, proof.get(), sizeof(G1J));
+  if (rc == ZK_OK) rc = zk_memcpy_d2h(ctx, proof_h, proof.get() + 1, (3 * (size_t)k_lo + 1) * sizeof(G1J));
+  if (rc == ZK_OK) rc = zk_memcpy_d2h(ctx, ret_h, ret.get(), sizeof(Fr));
+  gens_destroy(cg);
+  return rc;
+}
+int zk_msm_batch(zk_ctx* ctx, zk_gens* gens, const zk_fr* scalars, uint32_t q, zk_g1j* out) {
+  CHECK_CTX(ctx);
+  if (!gens) return ctx->fail(ZK_ERR_ARG, "null zk_gens");
+  if (q) { CHECK_PTR(ctx, scalars); CHECK_PTR(ctx, out); }
+  return msm_batch_dev(ctx, gens, F(scalars), q, /*do_unmont=*/false, /*probe_bits=*/false, J(out));
 }
 
 // ---------------------------------------------------------------- layers
@@ -501,26 +526,28 @@ int zk_float_to_fr(zk_ctx* ctx, const float* fs, zk_fr* out, uint32_t rows, uint
   if (!fs) return ctx->fail(ZK_ERR_ARG, "null pointer: fs_d");
   return float_to_fr_dev(ctx, fs, F(out), rows, rows_p, cols, cols_p);
 }
-int zk_fc_create(zk_ctx* ctx, uint32_t in, uint32_t out, const zk_fr* w, const zk_g1j* gens, uint32_t n_gens, zk_fc** out_fc) {
+int zk_fc_create(zk_ctx* ctx, uint32_t in, uint32_t out, const zk_fr* w, zk_gens* gens, zk_fc** out_fc) {
   CHECK_CTX(ctx);
-  CHECK_PTR(ctx, w); CHECK_PTR(ctx, gens); CHECK_HOST(ctx, out_fc);
-  return fc_create(ctx, in, out, F(w), J(gens), n_gens, out_fc);
+  if (!gens) return ctx->fail(ZK_ERR_ARG, "null zk_gens");
+  CHECK_PTR(ctx, w); CHECK_HOST(ctx, out_fc);
+  return fc_create(ctx, in, out, F(w), gens, out_fc);
 }
-int zk_fc_from_float(zk_ctx* ctx, uint32_t in, uint32_t out, const float* w, const zk_g1j* gens, uint32_t n_gens, zk_fc** out_fc) {
+int zk_fc_from_float(zk_ctx* ctx, uint32_t in, uint32_t out, const float* w, zk_gens* gens, zk_fc** out_fc) {
   CHECK_CTX(ctx);
-  CHECK_PTR(ctx, gens); CHECK_HOST(ctx, out_fc);
+  if (!gens) return ctx->fail(ZK_ERR_ARG, "null zk_gens");
+  CHECK_HOST(ctx, out_fc);
   if (!w) return ctx->fail(ZK_ERR_ARG, "null pointer: w_d");
   if (in == 0 || out == 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   uint32_t in_p = 1u << ceil_log2(in), out_p = 1u << ceil_log2(out);  // zkfc.cu:92-93
   ZK_ALLOC(ctx, wq, Fr, (size_t)in_p * out_p);
   ZK_TRY(float_to_fr_dev(ctx, w, wq.get(), in, in_p, out, out_p));
   ZK_TRY(fr_unary(ctx, OP_MONT, wq.get(), wq.get(), in_p * out_p));  // weights.mont(), zkfc.cu:99
-  return fc_create(ctx, in_p, out_p, wq.get(), J(gens), n_gens, out_fc);
+  return fc_create(ctx, in_p, out_p, wq.get(), gens, out_fc);
 }
 int zk_fc_destroy(zk_fc* fc) {
   if (!fc) return ZK_ERR_ARG;
   (void)hipFree(fc->weights);
-  (void)hipFree(fc->com);
+  gens_destroy(fc->com);
   delete fc;
   return ZK_OK;
 }
@@ -528,7 +555,7 @@ uint32_t zk_fc_in(const zk_fc* fc) { return fc ? fc->in : 0; }
 uint32_t zk_fc_out(const zk_fc* fc) { return fc ? fc->out : 0; }
 uint32_t zk_fc_com_size(const zk_fc* fc) { return fc ? fc->m : 0; }
 const zk_fr* zk_fc_weights(const zk_fc* fc) { return fc ? reinterpret_cast<const zk_fr*>(fc->weights) : nullptr; }
-const zk_g1j* zk_fc_com(const zk_fc* fc) { return fc ? reinterpret_cast<const zk_g1j*>(fc->com) : nullptr; }
+const zk_g1j* zk_fc_com(const zk_fc* fc) { return fc && fc->com ? reinterpret_cast<const zk_g1j*>(fc->com->pts) : nullptr; }
 int zk_fc_load_input(zk_ctx* ctx, uint32_t batch, uint32_t in_dim, const float* x, zk_fr* out) {
   CHECK_CTX(ctx);
   CHECK_PTR(ctx, out);
@@ -542,12 +569,12 @@ int zk_fc_forward(zk_ctx* ctx, const zk_fc* fc, const zk_fr* x, uint32_t xn, zk_
   CHECK_PTR(ctx, x); CHECK_PTR(ctx, z);
   return fc_forward(ctx, fc, F(x), xn, F(z));
 }
-int zk_fc_prove(zk_ctx* ctx, const zk_fc* fc, const zk_fr* x, uint32_t xn, const zk_fr* z, uint32_t zn, const zk_g1j* gens, uint32_t n_gens,
-                const zk_fr* u_bs_h, const zk_fr* u_in_h, const zk_fr* u_out_h, zk_transcript* tr) {
+int zk_fc_prove(zk_ctx* ctx, zk_fc* fc, const zk_fr* x, uint32_t xn, const zk_fr* z, uint32_t zn, zk_gens* gens, const zk_fr* u_bs_h,
+                const zk_fr* u_in_h, const zk_fr* u_out_h, zk_transcript* tr) {
   CHECK_CTX(ctx);
-  if (!fc || !tr) return ctx->fail(ZK_ERR_ARG, "null zk_fc / zk_transcript");
-  CHECK_PTR(ctx, x); CHECK_PTR(ctx, z); CHECK_PTR(ctx, gens);
-  return fc_prove(ctx, fc, F(x), xn, F(z), zn, J(gens), n_gens, u_bs_h, u_in_h, u_out_h, tr);
+  if (!fc || !tr || !gens) return ctx->fail(ZK_ERR_ARG, "null zk_fc / zk_gens / zk_transcript");
+  CHECK_PTR(ctx, x); CHECK_PTR(ctx, z);
+  return fc_prove(ctx, fc, F(x), xn, F(z), zn, gens, u_bs_h, u_in_h, u_out_h, tr);
 }
 int zk_relu_create(zk_ctx* ctx, zk_relu** out) {
   CHECK_CTX(ctx);

@@ -9,14 +9,38 @@
 //    "reference algorithm on MI355X" baseline.
 //  * ZK_MSM_PIPPENGER (msm.hip): bucket MSMs over shared bases and the flattened opening; same
 //    group elements, compared in affine-canonical form.
-#include "ctx.hpp"
+#include "layers.hpp"
 #include "dev_util.hpp"
 
 namespace zk {
 
-int commit_pippenger_dev(zk_ctx* ctx, const G1J* gens, uint32_t n, const Fr* t, uint32_t tn, G1J* out);
-int me_open_flat_dev(zk_ctx* ctx, const Fr* t, const G1J* gens, uint32_t n, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d);
-int g1_me_msm_dev(zk_ctx* ctx, const G1J* t, uint32_t n, const Fr* u_d, uint32_t k, G1J* dst_d);
+int commit_pippenger_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, uint32_t tn, G1J* out);
+int me_open_flat_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d);
+int g1_me_msm_dev(zk_ctx* ctx, zk_gens* pts, const Fr* u_d, uint32_t k, G1J* dst_d);
+
+int gens_create(zk_ctx* ctx, const G1J* gens_d, uint32_t n, bool copy, zk_gens** out) {
+  if (n == 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
+  zk_gens* g = new zk_gens();
+  g->ctx = ctx;
+  g->n = n;
+  if (hipMalloc((void**)&g->pts, (size_t)n * sizeof(G1J)) != hipSuccess) {
+    delete g;
+    return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: generators");
+  }
+  if (copy) ZK_HIP(ctx, hipMemcpyAsync(g->pts, gens_d, (size_t)n * sizeof(G1J), hipMemcpyDeviceToDevice, ctx->stream));
+  *out = g;
+  return ZK_OK;
+}
+void gens_destroy(zk_gens* g) {
+  if (!g) return;
+  if (g->ctx) (void)hipStreamSynchronize(g->ctx->stream);
+  for (auto& kv : g->tables) {
+    (void)hipFree(kv.second.pts);
+    (void)hipFree(kv.second.inf);
+  }
+  (void)hipFree(g->pts);
+  delete g;
+}
 
 // one 64-thread block per row: acc = sum_{i = l, l+64, ...} gens[i] * unmont(t[row*n+i]); ladder.
 __global__ void __launch_bounds__(64) k_commit_literal(const G1J* __restrict__ gens, uint32_t n, const Fr* __restrict__ t, G1J* __restrict__ out) {
@@ -37,11 +61,13 @@ __global__ void __launch_bounds__(64) k_commit_literal(const G1J* __restrict__ g
   if (l == 0) out[row] = s[0];
 }
 
-int commit_dev(zk_ctx* ctx, const G1J* gens, uint32_t n, const Fr* t, uint32_t tn, G1J* out) {
+int commit_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, uint32_t tn, G1J* out) {
+  const uint32_t n = g->n;
+  const G1J* gens = g->pts;
   if (n == 0 || tn % n != 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");  // commitment.cu:31
   uint32_t m = tn / n;
   if (m == 0) return ZK_OK;
-  if (ctx->msm_mode == ZK_MSM_PIPPENGER) return commit_pippenger_dev(ctx, gens, n, t, tn, out);
+  if (ctx->msm_mode == ZK_MSM_PIPPENGER) return commit_pippenger_dev(ctx, g, t, tn, out);
   ZK_LAUNCH(ctx, "commit_literal", 32ull * tn + 144ull * (n + m), k_commit_literal, dim3(m), dim3(64), 0, gens, n, t, out);
   return ZK_OK;
 }
@@ -91,16 +117,19 @@ static int me_open_literal_dev(zk_ctx* ctx, const Fr* t, const G1J* gens, uint32
 }
 
 // Commitment::me_open, commitment.cu:62-81
-int me_open_dev(zk_ctx* ctx, const Fr* t, const G1J* gens, uint32_t n, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d) {
+int me_open_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d) {
+  const uint32_t n = g->n;
   if (n == 0 || k > 31) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   if ((n >> k) == 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");  // a round would see an empty tensor
-  if (ctx->msm_mode == ZK_MSM_PIPPENGER) return me_open_flat_dev(ctx, t, gens, n, u_d, k, proof_d, ret_d);
-  return me_open_literal_dev(ctx, t, gens, n, u_d, k, proof_d, ret_d);
+  // the flattened form needs the full binary tree the prover always has (n == 2^k, commitment.cu:89);
+  // ragged sizes, which only the bare me_open API can produce, keep the reference's op sequence
+  if (ctx->msm_mode == ZK_MSM_PIPPENGER && k <= 20 && n == (1u << k)) return me_open_flat_dev(ctx, g, t, u_d, k, proof_d, ret_d);
+  return me_open_literal_dev(ctx, t, g->pts, n, u_d, k, proof_d, ret_d);
 }
 
 // Commitment::open, commitment.cu:83-92.  u = u_lo || u_hi with |u_hi| = ceilLog2(m).
-int open_dev(zk_ctx* ctx, const G1J* gens, uint32_t n, const Fr* t, uint32_t tn, const G1J* com, uint32_t m, const Fr* u_d, uint32_t k,
-             G1J* com_eval_d, G1J* proof_d, Fr* ret_d) {
+int open_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, uint32_t tn, zk_gens* com, const Fr* u_d, uint32_t k, G1J* com_eval_d, G1J* proof_d, Fr* ret_d) {
+  const uint32_t n = g->n, m = com->n;
   uint32_t k_hi = ceil_log2(m);
   if (k_hi > k) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   uint32_t k_lo = k - k_hi;
@@ -108,14 +137,14 @@ int open_dev(zk_ctx* ctx, const G1J* gens, uint32_t n, const Fr* t, uint32_t tn,
   const Fr* u_hi = u_d + k_lo;
   // com(u_hi): computed by the reference and dropped (commitment.cu:88); kept as timed work and
   // recorded in the transcript
-  if (ctx->msm_mode == ZK_MSM_PIPPENGER) ZK_TRY(g1_me_msm_dev(ctx, com, m, u_hi, k_hi, com_eval_d));
-  else ZK_TRY(g1_me_dev(ctx, com, m, u_hi, k_hi, com_eval_d));
+  if (ctx->msm_mode == ZK_MSM_PIPPENGER) ZK_TRY(g1_me_msm_dev(ctx, com, u_hi, k_hi, com_eval_d));
+  else ZK_TRY(g1_me_dev(ctx, com->pts, m, u_hi, k_hi, com_eval_d));
   if (k_lo > 31 || n != (1u << k_lo)) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");  // commitment.cu:89
   uint32_t fsz = fr_partial_me_size(tn, k_hi, n);
   if (fsz != n) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   ZK_ALLOC(ctx, folded, Fr, n);
   ZK_TRY(fr_partial_me_dev(ctx, t, tn, u_hi, k_hi, n, folded.get()));
-  return me_open_dev(ctx, folded.get(), gens, n, u_lo, k_lo, proof_d, ret_d);
+  return me_open_dev(ctx, g, folded.get(), u_lo, k_lo, proof_d, ret_d);
 }
 
 }  // namespace zk

@@ -33,7 +33,7 @@ struct zk_ctx {
   uint64_t rng_seed = 0;
   uint64_t rng_draw = 0;
   // MSM configuration
-  int msm_mode = ZK_MSM_LITERAL;
+  int msm_mode = ZK_MSM_PIPPENGER;
   uint32_t msm_window = 0;
   // timing
   hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -215,12 +215,6 @@ int sumcheck_bin_dev(zk_ctx* ctx, const Fr* a, uint32_t n, const Fr* u_d, const 
 int g1_sum_dev(zk_ctx* ctx, const G1J* a, uint32_t n, G1J* dst_d);
 int g1_me_dev(zk_ctx* ctx, const G1J* t, uint32_t n, const Fr* u_d, uint32_t k, G1J* dst_d);
 int g1_to_affine_dev(zk_ctx* ctx, const G1J* a, uint32_t n, G1A* out, uint8_t* inf);
-// commit.hip
-int commit_dev(zk_ctx* ctx, const G1J* gens, uint32_t n, const Fr* t, uint32_t tn, G1J* out);
-int me_open_dev(zk_ctx* ctx, const Fr* t, const G1J* gens, uint32_t n, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d);
-int open_dev(zk_ctx* ctx, const G1J* gens, uint32_t n, const Fr* t, uint32_t tn, const G1J* com, uint32_t m,
-             const Fr* u_d, uint32_t k, G1J* com_eval_d, G1J* proof_d, Fr* ret_d);
-
 // upload a host challenge vector (k may be 0)
 inline int upload_fr(zk_ctx* ctx, DBuf<Fr>& buf, const zk_fr* h, uint32_t k) {
   if (!buf.alloc(ctx, k ? k : 1)) return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: challenges");

@@ -135,7 +135,8 @@ int zk_transcript::ensure(size_t add_fr, size_t add_g1) {
 // ------------------------------------------------------------------ zkFC
 namespace zk {
 
-int fc_create(zk_ctx* ctx, uint32_t in, uint32_t out, const Fr* weights_d, const G1J* gens_d, uint32_t n_gens, zk_fc** out_fc) {
+int fc_create(zk_ctx* ctx, uint32_t in, uint32_t out, const Fr* weights_d, zk_gens* gens, zk_fc** out_fc) {
+  const uint32_t n_gens = gens->n;
   if (in == 0 || out == 0 || n_gens == 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   uint64_t wn = (uint64_t)in * out;
   if (wn > 0xffffffffull || wn % n_gens != 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");  // commitment.cu:31 via zkfc.cu:102
@@ -145,12 +146,12 @@ int fc_create(zk_ctx* ctx, uint32_t in, uint32_t out, const Fr* weights_d, const
   fc->out = out;
   fc->m = (uint32_t)(wn / n_gens);
   fc->n_gens = n_gens;
-  if (hipMalloc((void**)&fc->weights, wn * sizeof(Fr)) != hipSuccess || hipMalloc((void**)&fc->com, (size_t)fc->m * sizeof(G1J)) != hipSuccess) {
+  if (hipMalloc((void**)&fc->weights, wn * sizeof(Fr)) != hipSuccess || gens_create(ctx, nullptr, fc->m, false, &fc->com) != ZK_OK) {
     zk_fc_destroy(fc);
     return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: zkFC");
   }
   ZK_HIP(ctx, hipMemcpyAsync(fc->weights, weights_d, wn * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
-  int rc = commit_dev(ctx, gens_d, n_gens, fc->weights, (uint32_t)wn, fc->com);
+  int rc = commit_dev(ctx, gens, fc->weights, (uint32_t)wn, fc->com->pts);
   if (rc != ZK_OK) {
     zk_fc_destroy(fc);
     return rc;
@@ -170,8 +171,9 @@ int fc_forward(zk_ctx* ctx, const zk_fc* fc, const Fr* x, uint32_t xn, Fr* z) {
 }
 
 // zkFC::prove, zkfc.cu:128-145
-int fc_prove(zk_ctx* ctx, const zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint32_t zn, const G1J* gens, uint32_t n_gens,
+int fc_prove(zk_ctx* ctx, zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint32_t zn, zk_gens* gens,
              const zk_fr* u_bs_h, const zk_fr* u_in_h, const zk_fr* u_out_h, zk_transcript* tr) {
+  const uint32_t n_gens = gens->n;
   if (xn % fc->in != 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions 1");
   const uint32_t batch = xn / fc->in;
   const uint32_t k_bs = ceil_log2(batch), k_in = ceil_log2(fc->in), k_out = ceil_log2(fc->out);
@@ -211,7 +213,7 @@ int fc_prove(zk_ctx* ctx, const zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z
   tr->n_fr += 1;
   // generators.open(weights, com, u_out || u_in)
   if (k_out + k_in < ceil_log2(fc->m)) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
-  ZK_TRY(open_dev(ctx, gens, n_gens, fc->weights, wn, fc->com, fc->m, u_out, k_out + k_in, tr->g1_d + tr->n_g1, tr->g1_d + tr->n_g1 + 1, tr->fr_d + tr->n_fr));
+  ZK_TRY(open_dev(ctx, gens, fc->weights, wn, fc->com, u_out, k_out + k_in, tr->g1_d + tr->n_g1, tr->g1_d + tr->n_g1 + 1, tr->fr_d + tr->n_fr));
   tr->n_fr += 1;
   tr->n_g1 += 1 + 3 * (k_out + k_in - ceil_log2(fc->m)) + 1;
   return ZK_OK;

@@ -2,11 +2,26 @@
 #pragma once
 #include "ctx.hpp"
 
+namespace zk {
+struct G1Table {  // affine window table: pts[w*n + j] = 2^(c*w) * base_j ; inf[...] marks infinite bases
+  uint32_t n = 0, c = 0, W = 0;
+  G1A* pts = nullptr;
+  uint8_t* inf = nullptr;
+};
+}  // namespace zk
+
+struct zk_gens {  // Commitment (commitment.cuh:8-23): generator tensor + lazily built MSM tables
+  zk_ctx* ctx = nullptr;
+  uint32_t n = 0;
+  zk::G1J* pts = nullptr;
+  std::map<uint32_t, zk::G1Table> tables;  // keyed by window width c
+};
+
 struct zk_fc {  // zkFC, zkfc.cuh:16-33: padded weights (Montgomery, [in][out]) + their commitment
   zk_ctx* ctx = nullptr;
   uint32_t in = 0, out = 0, m = 0, n_gens = 0;
   zk::Fr* weights = nullptr;
-  zk::G1J* com = nullptr;
+  zk_gens* com = nullptr;  // the m commitment points, wrapped so com(u) can run as a table MSM
 };
 
 struct zk_relu {  // zkReLU, zkrelu.cuh:10-20: aux tensors of the last forward pass
@@ -36,9 +51,16 @@ struct zk_transcript {  // proof values in the order of SURVEY.md App. A.6, resi
 
 namespace zk {
 int float_to_fr_dev(zk_ctx* ctx, const float* fs, Fr* out, uint32_t rows, uint32_t rows_p, uint32_t cols, uint32_t cols_p);
-int fc_create(zk_ctx* ctx, uint32_t in, uint32_t out, const Fr* weights_d, const G1J* gens_d, uint32_t n_gens, zk_fc** out_fc);
+int gens_create(zk_ctx* ctx, const G1J* gens_d, uint32_t n, bool copy, zk_gens** out);
+void gens_destroy(zk_gens* g);
+int gens_table(zk_ctx* ctx, zk_gens* g, uint32_t c, uint32_t W, const G1Table** out);
+int msm_batch_dev(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_unmont, bool probe_bits, G1J* out);
+int commit_dev(zk_ctx* ctx, zk_gens* gens, const Fr* t, uint32_t tn, G1J* out);
+int me_open_dev(zk_ctx* ctx, zk_gens* gens, const Fr* t, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d);
+int open_dev(zk_ctx* ctx, zk_gens* gens, const Fr* t, uint32_t tn, zk_gens* com, const Fr* u_d, uint32_t k, G1J* com_eval_d, G1J* proof_d, Fr* ret_d);
+int fc_create(zk_ctx* ctx, uint32_t in, uint32_t out, const Fr* weights_d, zk_gens* gens, zk_fc** out_fc);
 int fc_forward(zk_ctx* ctx, const zk_fc* fc, const Fr* x, uint32_t xn, Fr* z);
-int fc_prove(zk_ctx* ctx, const zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint32_t zn, const G1J* gens, uint32_t n_gens,
+int fc_prove(zk_ctx* ctx, zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint32_t zn, zk_gens* gens,
              const zk_fr* u_bs_h, const zk_fr* u_in_h, const zk_fr* u_out_h, zk_transcript* tr);
 int relu_forward(zk_ctx* ctx, zk_relu* relu, const Fr* x, uint32_t n, Fr* z);
 int relu_prove(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const Fr* z, uint32_t n, const zk_fr* u_z_h, const zk_fr* v_z_h, const zk_fr* u_r_h,
