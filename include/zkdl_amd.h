@@ -213,6 +213,10 @@ int zk_transcript_read_affine(zk_transcript* tr, zk_g1a* g1_h, uint8_t* inf_h, s
 /* Fr checksum of the transcript: sum of all Fr entries plus, per G1 entry, its affine x and y limbs
  * folded into Fr -- the per-proof aggregate that ranks all-reduce in the multi-GPU bench */
 int zk_transcript_digest(zk_transcript* tr, zk_fr* out_h);
+/* the same digest left on the DEVICE as 8 uint64 lanes (one per 32-bit limb, zero-extended), enqueued
+ * on the context's stream without a host round trip: ranks all-reduce these lanes with ncclSum on
+ * uint64 (exact for < 2^32 ranks), then carry-propagate and reduce mod r locally */
+int zk_transcript_digest_dev(zk_transcript* tr, uint64_t* out8_d);
 
 #ifdef __cplusplus
 }

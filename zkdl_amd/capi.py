@@ -33,7 +33,7 @@ zk_set_msm_window zk_gens_create zk_gens_destroy zk_gens_size zk_gens_points zk_
 zk_fc_out zk_fc_com_size zk_fc_weights zk_fc_com zk_fc_load_input zk_fc_forward zk_fc_prove zk_relu_create
 zk_relu_destroy zk_relu_forward zk_relu_sign zk_relu_mag_bin zk_relu_rem_bin zk_relu_prove zk_transcript_create
 zk_transcript_destroy zk_transcript_reset zk_transcript_counts zk_transcript_read zk_transcript_read_affine
-zk_transcript_digest""".split()
+zk_transcript_digest zk_transcript_digest_dev""".split()
 
 
 class ZkError(RuntimeError):
@@ -502,6 +502,10 @@ class Transcript:
         out = np.zeros(8, dtype=np.uint32)
         self.zk._chk(self.zk.lib.zk_transcript_digest(self.h, _hp(out)))
         return out
+
+    def digest_dev(self, out8_ptr):
+        """Digest as 8 uint64 lanes written to device memory at `out8_ptr` (no host sync)."""
+        self.zk._chk(self.zk.lib.zk_transcript_digest_dev(self.h, _vp(out8_ptr)))
 
     def close(self):
         if self.h:

@@ -657,28 +657,15 @@ int zk_transcript_digest(zk_transcript* tr, zk_fr* out_h) {
   if (!tr) return ZK_ERR_ARG;
   zk_ctx* ctx = tr->ctx;
   CHECK_HOST(ctx, out_h);
-  std::vector<Fr> frs(tr->n_fr ? tr->n_fr : 1);
-  std::vector<G1A> aff(tr->n_g1 ? tr->n_g1 : 1);
-  std::vector<uint8_t> inf(tr->n_g1 ? tr->n_g1 : 1);
-  if (tr->n_fr) ZK_TRY(zk_memcpy_d2h(ctx, frs.data(), tr->fr_d, tr->n_fr * sizeof(Fr)));
-  ZK_TRY(zk_transcript_read_affine(tr, reinterpret_cast<zk_g1a*>(aff.data()), inf.data(), tr->n_g1));
-  Fr acc = fr_zero();
-  for (size_t i = 0; i < tr->n_fr; i++) acc = fr_add(acc, frs[i]);
-  for (size_t i = 0; i < tr->n_g1; i++) {
-    if (inf[i]) continue;
-    // fold the 2 x 384 affine bits into Fr as 224-bit chunks (each < r)
-    const uint32_t* w = aff[i].x.v;
-    for (int c = 0; c < 4; c++) {
-      const uint32_t* src = (c < 2 ? aff[i].x.v : aff[i].y.v);
-      Fr e = fr_zero();
-      int lo = (c & 1) ? 7 : 0, cnt = (c & 1) ? 5 : 7;
-      for (int j = 0; j < cnt; j++) e.v[j] = src[lo + j];
-      acc = fr_add(acc, e);
-    }
-    (void)w;
-  }
-  memcpy(out_h, &acc, sizeof(Fr));
-  return ZK_OK;
+  ZK_ALLOC(ctx, d, Fr, 1);
+  ZK_TRY(transcript_digest_dev(ctx, tr->fr_d, tr->n_fr, tr->g1_d, tr->n_g1, d.get(), nullptr));
+  return zk_memcpy_d2h(ctx, out_h, d.get(), sizeof(Fr));
+}
+int zk_transcript_digest_dev(zk_transcript* tr, uint64_t* out8_d) {
+  if (!tr) return ZK_ERR_ARG;
+  zk_ctx* ctx = tr->ctx;
+  if (!out8_d || (((uintptr_t)out8_d) & 7u)) return ctx->fail(ZK_ERR_ARG, "null or misaligned pointer: out8_d");
+  return transcript_digest_dev(ctx, tr->fr_d, tr->n_fr, tr->g1_d, tr->n_g1, nullptr, out8_d);
 }
 
 }  // extern "C"

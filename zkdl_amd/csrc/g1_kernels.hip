@@ -218,6 +218,10 @@ __global__ void __launch_bounds__(64) k_g1_to_affine(const G1J* __restrict__ a, 
     r.x = fp_zero();
     r.y = fp_zero();
     inf[i] = 1;
+  } else if (l_eq(p.z, fp_one())) {  // already canonical (every MSM result is): nothing to invert
+    r.x = p.x;
+    r.y = p.y;
+    inf[i] = 0;
   } else {
     Fp zi = fp_inv(p.z);
     Fp zi2 = fp_sqr(zi);

@@ -103,6 +103,39 @@ __global__ void __launch_bounds__(256) k_relu(const Fr* __restrict__ X, Fr* __re
   }
 }
 
+// ------------------------------------------------------------------ transcript digest
+// sum of all Fr entries + every G1 entry's affine x, y folded in as 224-bit chunks (each < r)
+__global__ void __launch_bounds__(256) k_digest(const Fr* __restrict__ fr, uint32_t n_fr, const G1A* __restrict__ aff, const uint8_t* __restrict__ inf, uint32_t n_g1,
+                                                 Fr* __restrict__ out_fr, uint64_t* __restrict__ out8) {
+  __shared__ Fr lds[4];
+  Fr acc = fr_zero();
+  for (uint32_t i = threadIdx.x; i < n_fr; i += blockDim.x) acc = fr_add(acc, fr[i]);
+  for (uint32_t i = threadIdx.x; i < 4 * n_g1; i += blockDim.x) {
+    uint32_t p = i >> 2, cidx = i & 3u;
+    if (inf[p]) continue;
+    const uint32_t* src = cidx < 2 ? aff[p].x.v : aff[p].y.v;
+    uint32_t lo = (cidx & 1u) ? 7u : 0u, cnt = (cidx & 1u) ? 5u : 7u;
+    Fr e = fr_zero();
+#pragma unroll
+    for (uint32_t j = 0; j < 7; j++) e.v[j] = j < cnt ? src[lo + j] : 0u;
+    acc = fr_add(acc, e);
+  }
+  acc = block_sum_fr(acc, lds);
+  if (threadIdx.x == 0) {
+    if (out_fr) *out_fr = acc;
+    if (out8)
+      for (int j = 0; j < 8; j++) out8[j] = acc.v[j];
+  }
+}
+int transcript_digest_dev(zk_ctx* ctx, const Fr* fr, size_t n_fr, const G1J* g1, size_t n_g1, Fr* out_fr_d, uint64_t* out8_d) {
+  ZK_ALLOC(ctx, aff, G1A, n_g1 ? n_g1 : 1);
+  ZK_ALLOC(ctx, inf, uint8_t, n_g1 ? n_g1 : 1);
+  if (n_g1) ZK_TRY(g1_to_affine_dev(ctx, g1, (uint32_t)n_g1, aff.get(), inf.get()));
+  ZK_LAUNCH(ctx, "transcript_digest", 32ull * n_fr + 96ull * n_g1, k_digest, dim3(1), dim3(256), 0, fr, (uint32_t)n_fr, (const G1A*)aff.get(), (const uint8_t*)inf.get(),
+            (uint32_t)n_g1, out_fr_d, out8_d);
+  return ZK_OK;
+}
+
 }  // namespace zk
 
 using namespace zk;
