@@ -205,6 +205,9 @@ int zk_relu_prove(zk_ctx* ctx, const zk_relu* relu, const zk_fr* x_d, const zk_f
 int zk_transcript_create(zk_ctx* ctx, zk_transcript** out);
 int zk_transcript_destroy(zk_transcript* tr);
 int zk_transcript_reset(zk_transcript* tr);
+/* With the PIPPENGER back end zk_fc_prove only ENQUEUES its MSMs; they run, all layers together, when
+ * the transcript is flushed -- explicitly here, or implicitly by counts / read / digest / reset. */
+int zk_transcript_flush(zk_transcript* tr);
 /* synchronises; counts of values appended so far */
 int zk_transcript_counts(zk_transcript* tr, size_t* n_fr, size_t* n_g1);
 int zk_transcript_read(zk_transcript* tr, zk_fr* fr_h, size_t fr_cap, zk_g1j* g1_h, size_t g1_cap);

@@ -32,7 +32,7 @@ zk_g1_madd_bcast zk_g1_msub_bcast zk_g1_sum zk_g1_mul zk_g1_mul_bcast zk_g1_me z
 zk_set_msm_window zk_gens_create zk_gens_destroy zk_gens_size zk_gens_points zk_commit zk_me_open zk_open zk_msm_batch zk_float_to_fr zk_fc_create zk_fc_from_float zk_fc_destroy zk_fc_in
 zk_fc_out zk_fc_com_size zk_fc_weights zk_fc_com zk_fc_load_input zk_fc_forward zk_fc_prove zk_relu_create
 zk_relu_destroy zk_relu_forward zk_relu_sign zk_relu_mag_bin zk_relu_rem_bin zk_relu_prove zk_transcript_create
-zk_transcript_destroy zk_transcript_reset zk_transcript_counts zk_transcript_read zk_transcript_read_affine
+zk_transcript_destroy zk_transcript_reset zk_transcript_flush zk_transcript_counts zk_transcript_read zk_transcript_read_affine
 zk_transcript_digest zk_transcript_digest_dev""".split()
 
 
@@ -478,6 +478,9 @@ class Transcript:
 
     def reset(self):
         self.zk.lib.zk_transcript_reset(self.h)
+
+    def flush(self):
+        self.zk._chk(self.zk.lib.zk_transcript_flush(self.h))
 
     def counts(self):
         a, b = _sz(), _sz()

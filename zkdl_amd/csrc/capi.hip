@@ -485,7 +485,7 @@ int zk_me_open(zk_ctx* ctx, zk_gens* gens, const zk_fr* t, const zk_fr* u_h, uin
   ZK_TRY(upload_fr(ctx, u, u_h, k));
   ZK_ALLOC(ctx, proof, G1J, 3 * (size_t)k + 1);
   ZK_ALLOC(ctx, ret, Fr, 1);
-  ZK_TRY(me_open_dev(ctx, gens, F(t), u.get(), k, proof.get(), ret.get()));
+  ZK_TRY(me_open_dev(ctx, gens, F(t), u.get(), k, proof.get(), ret.get(), nullptr));
   ZK_TRY(zk_memcpy_d2h(ctx, proof_h, proof.get(), (3 * (size_t)k + 1) * sizeof(G1J)));
   return zk_memcpy_d2h(ctx, ret_h, ret.get(), sizeof(Fr));
 }
@@ -505,7 +505,7 @@ int zk_open(zk_ctx* ctx, zk_gens* gens, const zk_fr* t, uint32_t tn, const zk_g1
   ZK_ALLOC(ctx, ret, Fr, 1);
   zk_gens* cg = nullptr;  // ad-hoc handle over the caller's commitment tensor (zkFC keeps a persistent one)
   ZK_TRY(gens_create(ctx, J(com), m, true, &cg));
-  int rc = open_dev(ctx, gens, F(t), tn, cg, u.get(), k, proof.get(), proof.get() + 1, ret.get());
+  int rc = open_dev(ctx, gens, F(t), tn, cg, u.get(), k, proof.get(), proof.get() + 1, ret.get(), nullptr);
   if (rc == ZK_OK) rc = zk_memcpy_d2h(ctx, com_eval_h, proof.get(), sizeof(G1J));
   if (rc == ZK_OK) rc = zk_memcpy_d2h(ctx, proof_h, proof.get() + 1, (3 * (size_t)k_lo + 1) * sizeof(G1J));
   if (rc == ZK_OK) rc = zk_memcpy_d2h(ctx, ret_h, ret.get(), sizeof(Fr));
@@ -617,6 +617,7 @@ int zk_transcript_create(zk_ctx* ctx, zk_transcript** out) {
 }
 int zk_transcript_destroy(zk_transcript* tr) {
   if (!tr) return ZK_ERR_ARG;
+  (void)tr->flush();
   if (tr->fr_d) (void)hipFreeAsync(tr->fr_d, tr->ctx->stream);
   if (tr->g1_d) (void)hipFreeAsync(tr->g1_d, tr->ctx->stream);
   delete tr;
@@ -624,11 +625,17 @@ int zk_transcript_destroy(zk_transcript* tr) {
 }
 int zk_transcript_reset(zk_transcript* tr) {
   if (!tr) return ZK_ERR_ARG;
-  tr->n_fr = tr->n_g1 = 0;
-  return ZK_OK;
+  int rc = tr->flush();  // pending MSMs own scratch that must be released in stream order
+  tr->n_fr = tr->n_g1 = tr->n_g1_final = 0;
+  return rc;
+}
+int zk_transcript_flush(zk_transcript* tr) {
+  if (!tr) return ZK_ERR_ARG;
+  return tr->flush();
 }
 int zk_transcript_counts(zk_transcript* tr, size_t* n_fr, size_t* n_g1) {
   if (!tr) return ZK_ERR_ARG;
+  ZK_TRY(tr->flush());
   ZK_HIP(tr->ctx, hipStreamSynchronize(tr->ctx->stream));
   if (n_fr) *n_fr = tr->n_fr;
   if (n_g1) *n_g1 = tr->n_g1;
@@ -638,6 +645,7 @@ int zk_transcript_read(zk_transcript* tr, zk_fr* fr_h, size_t fr_cap, zk_g1j* g1
   if (!tr) return ZK_ERR_ARG;
   zk_ctx* ctx = tr->ctx;
   if (fr_cap < tr->n_fr || g1_cap < tr->n_g1) return ctx->fail(ZK_ERR_ARG, "transcript buffers too small");
+  ZK_TRY(tr->flush());
   if (tr->n_fr) ZK_TRY(zk_memcpy_d2h(ctx, fr_h, tr->fr_d, tr->n_fr * sizeof(Fr)));
   if (tr->n_g1) ZK_TRY(zk_memcpy_d2h(ctx, g1_h, tr->g1_d, tr->n_g1 * sizeof(G1J)));
   return zk_ctx_sync(ctx);
@@ -646,6 +654,7 @@ int zk_transcript_read_affine(zk_transcript* tr, zk_g1a* g1_h, uint8_t* inf_h, s
   if (!tr) return ZK_ERR_ARG;
   zk_ctx* ctx = tr->ctx;
   if (cap < tr->n_g1) return ctx->fail(ZK_ERR_ARG, "transcript buffers too small");
+  ZK_TRY(tr->flush());
   if (!tr->n_g1) return zk_ctx_sync(ctx);
   ZK_ALLOC(ctx, aff, G1A, tr->n_g1);
   ZK_ALLOC(ctx, inf, uint8_t, tr->n_g1);
@@ -657,6 +666,7 @@ int zk_transcript_digest(zk_transcript* tr, zk_fr* out_h) {
   if (!tr) return ZK_ERR_ARG;
   zk_ctx* ctx = tr->ctx;
   CHECK_HOST(ctx, out_h);
+  ZK_TRY(tr->flush());
   ZK_ALLOC(ctx, d, Fr, 1);
   ZK_TRY(transcript_digest_dev(ctx, tr->fr_d, tr->n_fr, tr->g1_d, tr->n_g1, d.get(), nullptr));
   return zk_memcpy_d2h(ctx, out_h, d.get(), sizeof(Fr));
@@ -665,6 +675,7 @@ int zk_transcript_digest_dev(zk_transcript* tr, uint64_t* out8_d) {
   if (!tr) return ZK_ERR_ARG;
   zk_ctx* ctx = tr->ctx;
   if (!out8_d || (((uintptr_t)out8_d) & 7u)) return ctx->fail(ZK_ERR_ARG, "null or misaligned pointer: out8_d");
+  ZK_TRY(tr->flush());
   return transcript_digest_dev(ctx, tr->fr_d, tr->n_fr, tr->g1_d, tr->n_g1, nullptr, out8_d);
 }
 

@@ -15,8 +15,8 @@
 namespace zk {
 
 int commit_pippenger_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, uint32_t tn, G1J* out);
-int me_open_flat_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d);
-int g1_me_msm_dev(zk_ctx* ctx, zk_gens* pts, const Fr* u_d, uint32_t k, G1J* dst_d);
+int me_open_flat_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d, MsmQueue* queue);
+int g1_me_msm_dev(zk_ctx* ctx, zk_gens* pts, const Fr* u_d, uint32_t k, G1J* dst_d, MsmQueue* queue);
 
 int gens_create(zk_ctx* ctx, const G1J* gens_d, uint32_t n, bool copy, zk_gens** out) {
   if (n == 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
@@ -117,18 +117,18 @@ static int me_open_literal_dev(zk_ctx* ctx, const Fr* t, const G1J* gens, uint32
 }
 
 // Commitment::me_open, commitment.cu:62-81
-int me_open_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d) {
+int me_open_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d, MsmQueue* queue) {
   const uint32_t n = g->n;
   if (n == 0 || k > 31) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   if ((n >> k) == 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");  // a round would see an empty tensor
   // the flattened form needs the full binary tree the prover always has (n == 2^k, commitment.cu:89);
   // ragged sizes, which only the bare me_open API can produce, keep the reference's op sequence
-  if (ctx->msm_mode == ZK_MSM_PIPPENGER && k <= 20 && n == (1u << k)) return me_open_flat_dev(ctx, g, t, u_d, k, proof_d, ret_d);
+  if (ctx->msm_mode == ZK_MSM_PIPPENGER && k <= 19 && n == (1u << k)) return me_open_flat_dev(ctx, g, t, u_d, k, proof_d, ret_d, queue);
   return me_open_literal_dev(ctx, t, g->pts, n, u_d, k, proof_d, ret_d);
 }
 
 // Commitment::open, commitment.cu:83-92.  u = u_lo || u_hi with |u_hi| = ceilLog2(m).
-int open_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, uint32_t tn, zk_gens* com, const Fr* u_d, uint32_t k, G1J* com_eval_d, G1J* proof_d, Fr* ret_d) {
+int open_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, uint32_t tn, zk_gens* com, const Fr* u_d, uint32_t k, G1J* com_eval_d, G1J* proof_d, Fr* ret_d, MsmQueue* queue) {
   const uint32_t n = g->n, m = com->n;
   uint32_t k_hi = ceil_log2(m);
   if (k_hi > k) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
@@ -137,14 +137,14 @@ int open_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, uint32_t tn, zk_gens* com, co
   const Fr* u_hi = u_d + k_lo;
   // com(u_hi): computed by the reference and dropped (commitment.cu:88); kept as timed work and
   // recorded in the transcript
-  if (ctx->msm_mode == ZK_MSM_PIPPENGER) ZK_TRY(g1_me_msm_dev(ctx, com, u_hi, k_hi, com_eval_d));
+  if (ctx->msm_mode == ZK_MSM_PIPPENGER) ZK_TRY(g1_me_msm_dev(ctx, com, u_hi, k_hi, com_eval_d, queue));
   else ZK_TRY(g1_me_dev(ctx, com->pts, m, u_hi, k_hi, com_eval_d));
   if (k_lo > 31 || n != (1u << k_lo)) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");  // commitment.cu:89
   uint32_t fsz = fr_partial_me_size(tn, k_hi, n);
   if (fsz != n) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   ZK_ALLOC(ctx, folded, Fr, n);
   ZK_TRY(fr_partial_me_dev(ctx, t, tn, u_hi, k_hi, n, folded.get()));
-  return me_open_dev(ctx, g, folded.get(), u_lo, k_lo, proof_d, ret_d);
+  return me_open_dev(ctx, g, folded.get(), u_lo, k_lo, proof_d, ret_d, queue);
 }
 
 }  // namespace zk

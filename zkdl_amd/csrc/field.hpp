@@ -223,6 +223,54 @@ ZK_HD El<F> f_mul(const El<F>& a, const El<F>& b) {
   for (int i = 0; i < N; i++) r.v[i] = t[i];
   return f_reduce_once<F>(r);
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- gfx950 Montgomery product: product scanning (FIPS) with a 96-bit column accumulator.
+// Measured on MI355X (tools/instr_rate.hip): v_mad_u64_u32 issues every ~4.6 cycles per wave, the
+// same as a carry add, a 64-bit add or a VOP3 move-class op -- so the cost of a big-integer multiply
+// is its INSTRUCTION COUNT, not its multiplies.  Operand-scanning CIOS compiles to 1 MAD + 1 64-bit
+// add + ~2.5 moves per partial product; here every partial product is exactly
+//     v_mad_u64_u32  acc[63:0], vcc, x, y, acc[63:0]      (64-bit accumulate, carry out in vcc)
+//     v_addc_co_u32  acc[95:64], vcc, 0, acc[95:64], vcc
+// and a column shift is three moves.  The value computed is (a*b + m*p) / R with the same m as
+// CIOS, so limbs (including the discarded overflow limb) are identical to the reference's.
+#define ZK_MAC_VV(lo, hi, x, y) \
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(x), "v"(y) : "vcc")
+#define ZK_MAC_VS(lo, hi, x, sy) \
+  asm("v_mad_u64_u32 %0, vcc, %3, %2, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(x), "s"(sy) : "vcc")
+
+template <class F>
+__device__ __forceinline__ El<F> f_mul_dev(const El<F>& a, const El<F>& b) {
+  constexpr int N = F::N;
+  uint32_t m[N];
+  El<F> t;
+  uint64_t lo = 0;
+  uint32_t hi = 0;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) ZK_MAC_VV(lo, hi, a.v[i], b.v[k - i]);
+#pragma unroll
+    for (int i = 0; i < k; i++) ZK_MAC_VS(lo, hi, m[i], F::P(k - i));
+    m[k] = (uint32_t)lo * F::INV;
+    ZK_MAC_VS(lo, hi, m[k], F::P(0));  // clears the low word
+    lo = (lo >> 32) | ((uint64_t)hi << 32);
+    hi = 0;
+  }
+#pragma unroll
+  for (int k = N; k < 2 * N - 1; k++) {
+#pragma unroll
+    for (int i = k - N + 1; i < N; i++) ZK_MAC_VV(lo, hi, a.v[i], b.v[k - i]);
+#pragma unroll
+    for (int i = k - N + 1; i < N; i++) ZK_MAC_VS(lo, hi, m[i], F::P(k - i));
+    t.v[k - N] = (uint32_t)lo;
+    lo = (lo >> 32) | ((uint64_t)hi << 32);
+    hi = 0;
+  }
+  t.v[N - 1] = (uint32_t)lo;  // (lo >> 32) is the overflow limb the reference drops as well
+  return f_reduce_once<F>(t);
+}
+#endif
+
 template <class F>
 ZK_HD El<F> f_sqr(const El<F>& a) {
   return f_mul<F>(a, a);
@@ -245,7 +293,14 @@ ZK_HD El<F> f_unmont(const El<F>& a) {
 // Short names used throughout the kernels.
 ZK_HD Fr fr_add(const Fr& a, const Fr& b) { return f_add<FrP>(a, b); }
 ZK_HD Fr fr_sub(const Fr& a, const Fr& b) { return f_sub<FrP>(a, b); }
-static ZK_HD_CALL Fr fr_mul(const Fr& a, const Fr& b) { return f_mul<FrP>(a, b); }
+// Fr products are inlined into the streaming kernels (~330 instructions each).
+ZK_HD Fr fr_mul(const Fr& a, const Fr& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return f_mul_dev<FrP>(a, b);
+#else
+  return f_mul<FrP>(a, b);
+#endif
+}
 ZK_HD Fr fr_sqr(const Fr& a) { return fr_mul(a, a); }
 ZK_HD Fr fr_neg(const Fr& a) { return f_neg<FrP>(a); }
 ZK_HD Fr fr_dbl(const Fr& a) { return f_double<FrP>(a); }
@@ -264,7 +319,30 @@ ZK_HD Fr fr_zero() { return f_zero<FrP>(); }
 ZK_HD Fr fr_one() { return f_one<FrP>(); }
 ZK_HD Fp fp_add(const Fp& a, const Fp& b) { return f_add<FpP>(a, b); }
 ZK_HD Fp fp_sub(const Fp& a, const Fp& b) { return f_sub<FpP>(a, b); }
-static ZK_HD_CALL Fp fp_mul(const Fp& a, const Fp& b) { return f_mul<FpP>(a, b); }
+// The Fp product is a real device CALL (a Jacobian add holds 16 of them) whose 24 operand limbs
+// travel in VGPRs: clang passes non-aggregate vector arguments directly, whereas two 48-byte structs
+// would exceed its 16-register aggregate budget and go through scratch memory.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef uint32_t zk_u32x4 __attribute__((ext_vector_type(4)));
+static __device__ __attribute__((noinline)) Fp fp_mul_regs(zk_u32x4 a0, zk_u32x4 a1, zk_u32x4 a2, zk_u32x4 b0, zk_u32x4 b1, zk_u32x4 b2) {
+  Fp a, b;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    a.v[i] = a0[i]; a.v[4 + i] = a1[i]; a.v[8 + i] = a2[i];
+    b.v[i] = b0[i]; b.v[4 + i] = b1[i]; b.v[8 + i] = b2[i];
+  }
+  return f_mul_dev<FpP>(a, b);
+}
+#endif
+ZK_HD Fp fp_mul(const Fp& a, const Fp& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  zk_u32x4 a0 = {a.v[0], a.v[1], a.v[2], a.v[3]}, a1 = {a.v[4], a.v[5], a.v[6], a.v[7]}, a2 = {a.v[8], a.v[9], a.v[10], a.v[11]};
+  zk_u32x4 b0 = {b.v[0], b.v[1], b.v[2], b.v[3]}, b1 = {b.v[4], b.v[5], b.v[6], b.v[7]}, b2 = {b.v[8], b.v[9], b.v[10], b.v[11]};
+  return fp_mul_regs(a0, a1, a2, b0, b1, b2);
+#else
+  return f_mul<FpP>(a, b);
+#endif
+}
 ZK_HD Fp fp_sqr(const Fp& a) { return fp_mul(a, a); }
 ZK_HD Fp fp_neg(const Fp& a) { return f_neg<FpP>(a); }
 ZK_HD Fp fp_dbl(const Fp& a) { return f_double<FpP>(a); }

@@ -26,7 +26,7 @@ ZK_HD G1J g1_zero() {
 }
 ZK_HD bool g1_is_inf(const G1J& a) { return l_is_zero(a.z); }
 
-static ZK_HD_CALL G1J g1_double(const G1J& q) {
+ZK_HD G1J g1_double(const G1J& q) {
   if (l_is_zero(q.z)) return q;
   Fp a = fp_sqr(q.x);
   Fp b = fp_sqr(q.y);
@@ -45,7 +45,7 @@ static ZK_HD_CALL G1J g1_double(const G1J& q) {
   return o;
 }
 
-static ZK_HD_CALL G1J g1_add(const G1J& a, const G1J& b) {
+ZK_HD G1J g1_add(const G1J& a, const G1J& b) {
   if (l_is_zero(a.z)) return b;
   if (l_is_zero(b.z)) return a;
   Fp z1z1 = fp_sqr(a.z);
@@ -71,7 +71,7 @@ static ZK_HD_CALL G1J g1_add(const G1J& a, const G1J& b) {
   return o;
 }
 
-static ZK_HD_CALL G1J g1_add_mixed(const G1J& a, const G1A& b) {
+ZK_HD G1J g1_add_mixed(const G1J& a, const G1A& b) {
   if (l_is_zero(a.z)) {
     G1J o;
     o.x = b.x;
@@ -119,7 +119,7 @@ ZK_HD uint32_t fr_limb(const Fr& x, uint32_t w) {
   return r;
 }
 
-static ZK_HD_CALL G1J g1_mul_naive(G1J a, const Fr& x) {
+ZK_HD G1J g1_mul_naive(G1J a, const Fr& x) {
   G1J out = g1_zero();
 #pragma unroll 1
   for (uint32_t w = 0; w < 8; w++) {

@@ -153,7 +153,8 @@ int zk_transcript::ensure(size_t add_fr, size_t add_g1) {
     cap_fr = nc;
   }
   if (n_g1 + add_g1 > cap_g1) {
-    size_t nc = cap_g1 ? cap_g1 : 256;
+    ZK_TRY(flush());  // queued MSMs write into g1_d: settle them before the buffer moves
+    size_t nc = cap_g1 ? cap_g1 : 1024;
     while (nc < n_g1 + add_g1) nc *= 2;
     G1J* p = nullptr;
     ZK_HIP(ctx, hipMallocAsync((void**)&p, nc * sizeof(G1J), ctx->stream));
@@ -162,6 +163,13 @@ int zk_transcript::ensure(size_t add_fr, size_t add_g1) {
     g1_d = p;
     cap_g1 = nc;
   }
+  return ZK_OK;
+}
+
+int zk_transcript::flush() {
+  ZK_TRY(msm_flush(ctx, &queue));
+  if (n_g1 > n_g1_final && ctx->msm_mode == ZK_MSM_PIPPENGER) ZK_TRY(g1_canonicalise_dev(ctx, g1_d + n_g1_final, (uint32_t)(n_g1 - n_g1_final)));
+  n_g1_final = n_g1;
   return ZK_OK;
 }
 
@@ -246,7 +254,7 @@ int fc_prove(zk_ctx* ctx, zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint
   tr->n_fr += 1;
   // generators.open(weights, com, u_out || u_in)
   if (k_out + k_in < ceil_log2(fc->m)) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
-  ZK_TRY(open_dev(ctx, gens, fc->weights, wn, fc->com, u_out, k_out + k_in, tr->g1_d + tr->n_g1, tr->g1_d + tr->n_g1 + 1, tr->fr_d + tr->n_fr));
+  ZK_TRY(open_dev(ctx, gens, fc->weights, wn, fc->com, u_out, k_out + k_in, tr->g1_d + tr->n_g1, tr->g1_d + tr->n_g1 + 1, tr->fr_d + tr->n_fr, &tr->queue));
   tr->n_fr += 1;
   tr->n_g1 += 1 + 3 * (k_out + k_in - ceil_log2(fc->m)) + 1;
   return ZK_OK;

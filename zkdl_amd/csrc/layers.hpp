@@ -10,6 +10,20 @@ struct G1Table {  // affine window table: pts[w*n + j] = 2^(c*w) * base_j ; inf[
 };
 }  // namespace zk
 
+namespace zk {
+struct MsmJobHost {  // one pending MSM: *out = sum_j mags[j] * base_j over table T (W windows in use)
+  const G1Table* T;
+  const Fr* mags;
+  G1J* out;
+  uint32_t W;
+};
+struct MsmQueue {  // MSMs enqueued by the provers, executed together by msm_flush()
+  std::vector<MsmJobHost> jobs;
+  std::vector<DBuf<Fr>> keep;  // prepared scalars, alive until the flush
+  uint32_t c = 0;
+};
+}  // namespace zk
+
 struct zk_gens {  // Commitment (commitment.cuh:8-23): generator tensor + lazily built MSM tables
   zk_ctx* ctx = nullptr;
   uint32_t n = 0;
@@ -46,7 +60,10 @@ struct zk_transcript {  // proof values in the order of SURVEY.md App. A.6, resi
   zk::Fr* fr_d = nullptr;
   zk::G1J* g1_d = nullptr;
   size_t n_fr = 0, n_g1 = 0, cap_fr = 0, cap_g1 = 0;
+  zk::MsmQueue queue;      // deferred MSMs whose results land in g1_d
+  size_t n_g1_final = 0;   // G1 entries already flushed + canonicalised
   int ensure(size_t add_fr, size_t add_g1);
+  int flush();             // run pending MSMs, canonicalise their outputs
 };
 
 namespace zk {
@@ -56,9 +73,13 @@ int gens_create(zk_ctx* ctx, const G1J* gens_d, uint32_t n, bool copy, zk_gens**
 void gens_destroy(zk_gens* g);
 int gens_table(zk_ctx* ctx, zk_gens* g, uint32_t c, uint32_t W, const G1Table** out);
 int msm_batch_dev(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_unmont, bool probe_bits, G1J* out);
+int msm_enqueue(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_unmont, bool probe_bits, G1J* out, MsmQueue* queue);
+int msm_flush(zk_ctx* ctx, MsmQueue* queue);
+int g1_canonicalise_dev(zk_ctx* ctx, G1J* pts, uint32_t n);
 int commit_dev(zk_ctx* ctx, zk_gens* gens, const Fr* t, uint32_t tn, G1J* out);
-int me_open_dev(zk_ctx* ctx, zk_gens* gens, const Fr* t, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d);
-int open_dev(zk_ctx* ctx, zk_gens* gens, const Fr* t, uint32_t tn, zk_gens* com, const Fr* u_d, uint32_t k, G1J* com_eval_d, G1J* proof_d, Fr* ret_d);
+// queue == nullptr: run now; otherwise (PIPPENGER back end) the MSMs are deferred to msm_flush(queue)
+int me_open_dev(zk_ctx* ctx, zk_gens* gens, const Fr* t, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d, MsmQueue* queue);
+int open_dev(zk_ctx* ctx, zk_gens* gens, const Fr* t, uint32_t tn, zk_gens* com, const Fr* u_d, uint32_t k, G1J* com_eval_d, G1J* proof_d, Fr* ret_d, MsmQueue* queue);
 int fc_create(zk_ctx* ctx, uint32_t in, uint32_t out, const Fr* weights_d, zk_gens* gens, zk_fc** out_fc);
 int fc_forward(zk_ctx* ctx, const zk_fc* fc, const Fr* x, uint32_t xn, Fr* z);
 int fc_prove(zk_ctx* ctx, zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint32_t zn, zk_gens* gens,

@@ -2,34 +2,42 @@
 // for gfx950, and the commitment/opening paths built on it (ZK_MSM_PIPPENGER back end).
 //
 // What the reference does: one 256-step double-and-add per (generator, scalar) pair, then sums
-// (g1-tensor.cu:422-445, commitment.cu:3-81) -- m*n independent 19-us-latency chains for commit and
-// five chained scalar-muls per thread per round for me_open.  What this file does instead:
+// (g1-tensor.cu:422-445, commitment.cu:3-81) -- m*n independent ~10-ms chains for commit and five
+// chained scalar-muls per thread per round for me_open.  What this file does instead:
 //
-//  * Window tables.  Every MSM on the path runs over a FIXED generator set (a layer's generators,
-//    or a layer's commitment points), so 2^(c*w) * G_j is precomputed once per set, in affine form
-//    (zk_gens, built lazily).  All windows of an MSM then share ONE bucket set and there is no
-//    Horner doubling chain on the critical path.
-//  * Signed digits.  A scalar s < r is first folded to (sign, min(s, r-s)) so the quantised weights
-//    (|w| < 2^13, half of them "negative" = r - |w|) need one or two windows, then recoded to digits
-//    in [-2^(c-1), 2^(c-1)) by the add-a-constant trick (no inter-window carries): 2^(c-1) buckets.
-//  * Per (MSM, window) workgroup: digit histogram + exclusive scan + scatter in LDS -> items grouped by
-//    bucket (k_msm_sort).  Per (MSM, bucket) lane: mixed additions of its items (k_msm_accum).
+//  * Window tables.  Every MSM on the path runs over a FIXED point set (a layer's generators, or a
+//    layer's commitment points), so 2^(c*w) * G_j is precomputed once per set in affine form (zk_gens,
+//    built lazily).  All windows of an MSM then share ONE bucket set: no Horner doubling chain over
+//    windows on the critical path.
+//  * Signed digits.  A scalar s < r is folded to (sign, min(s, r-s)) -- so quantised weights
+//    (|w| < 2^13, half of them stored as r - |w|) need two 7-bit windows instead of 37 -- then recoded
+//    to digits in [-2^(c-1), 2^(c-1)) by adding one constant (no inter-window carries): 2^(c-1) buckets.
+//  * Skew-proof accumulation.  A single G1 mixed add has ~28 us latency on one wave, so the critical
+//    path is what matters.  Per MSM, ONE workgroup counting-sorts all (point, window) items by bucket
+//    in LDS (k_msm_sort); then each LANE takes a fixed-size chunk of L consecutive items of the sorted
+//    list (k_msm_accum: every lane does exactly L mixed adds whatever the digit distribution -- a
+//    partially filled top window or repeated scalars cannot overload a lane); buckets that straddle
+//    chunks are stitched from per-chunk head/tail partials (k_msm_combine).
 //  * Bucket reduction without a running-sum chain: sum_b b*S_b = sum_i 2^i * (sum of buckets whose
-//    index has bit i), i.e. c independent tree sums (k_msm_bits, LDS tree) + a c-step Horner
-//    (k_msm_horner).
-//  * Flattened opening.  Every value Commitment::me_open pushes (T, T0, T1 per round and the final
-//    folded generator) is a linear combination of the ORIGINAL generators with scalars computable in
-//    Fr alone (derivation in DESIGN.md "Flattened opening"), so all 3k+1 of them are ONE batched MSM
-//    instead of k dependent rounds of scalar-muls.
+//    index has bit i): c independent LDS tree sums (k_msm_bits) + a c-step Horner (k_msm_horner).
+//  * Deferred batching.  Nothing in the protocol consumes a G1 value (the reference drops them all),
+//    so zkFC::prove only ENQUEUES its MSMs as jobs; every MSM of a whole proof (all layers, ~270 of
+//    them over 16 different tables) is executed by one sort/accum/combine/bits/horner sequence when the
+//    transcript is read, digested or flushed.
+//  * Flattened opening.  Every value Commitment::me_open pushes (T, T0, T1 per round, the final folded
+//    generator) is a linear combination of the ORIGINAL generators with scalars computable in Fr alone
+//    (DESIGN.md "Flattened opening"): 3k+1 independent MSMs instead of k dependent rounds.
 //
 // Same group elements as the reference, different Jacobian representatives: results are emitted in
 // canonical form (affine x, y with Z = ONE; infinity as {0, ONE, 0}) and compared affine-canonically.
-// All of this is integer-VALU bound (v_mad_u64_u32), not HBM bound; bases stay L2/MALL resident.
+// All of this is integer-VALU bound (v_mad_u64_u32), not HBM bound; tables stay L2/MALL resident.
 #include "layers.hpp"
 
 #include "dev_util.hpp"
 
 namespace zk {
+
+static constexpr uint32_t MSM_CHUNK = 16;  // items per lane in k_msm_accum
 
 // ------------------------------------------------------------------ window tables
 // jac[w*n + j] = 2^(c*w) * gens[j]
@@ -50,11 +58,6 @@ int gens_table(zk_ctx* ctx, zk_gens* g, uint32_t c, uint32_t W, const G1Table** 
     *out = &it->second;
     return ZK_OK;
   }
-  if (it != g->tables.end()) {
-    (void)hipFree(it->second.pts);
-    (void)hipFree(it->second.inf);
-    g->tables.erase(it);
-  }
   G1Table T;
   T.n = g->n;
   T.c = c;
@@ -66,6 +69,16 @@ int gens_table(zk_ctx* ctx, zk_gens* g, uint32_t c, uint32_t W, const G1Table** 
     ZK_ALLOC(ctx, jac, G1J, total);
     ZK_LAUNCH(ctx, "msm_table_build", 144ull * total, k_table_chain, dim3((g->n + 63) / 64), dim3(64), 0, (const G1J*)g->pts, g->n, c, W, jac.get());
     ZK_TRY(g1_to_affine_dev(ctx, jac.get(), (uint32_t)total, T.pts, T.inf));
+  }
+  if (it != g->tables.end()) {
+    // a wider table replaces a narrower one IN PLACE: queued jobs hold a pointer to this map node and
+    // pick up the new (superset) arrays when they run; the old arrays go once the stream has drained
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(it->second.pts);
+    (void)hipFree(it->second.inf);
+    it->second = T;
+    *out = &it->second;
+    return ZK_OK;
   }
   g->tables[c] = T;
   *out = &g->tables[c];
@@ -79,7 +92,7 @@ __global__ void __launch_bounds__(256) k_scalar_prep(const Fr* __restrict__ s, F
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
     Fr v = s[i];
     if (do_unmont) v = fr_unmont(v);
-    Fr nv = fr_neg(v);  // r - v (0 for v == 0)
+    Fr nv = fr_neg(v);         // r - v (0 for v == 0)
     bool neg = !l_gte(nv, v);  // r - v < v
     Fr m = neg ? nv : v;
     uint32_t len = 0;
@@ -98,8 +111,7 @@ __global__ void __launch_bounds__(256) k_scalar_prep(const Fr* __restrict__ s, F
   if ((threadIdx.x & 63u) == 0 && mx) atomicMax(maxbits, mx);
 }
 
-// K = sum_{w < Wk} 2^(c*w + c - 1): adding it makes every c-bit window of mag + K equal to
-// (signed digit + 2^(c-1)), with no carry dependence between windows.
+// K = sum_{w < W} 2^(c*w + c - 1): every c-bit window of mag + K equals (signed digit + 2^(c-1)).
 struct RecodeK {
   uint32_t v[9];
 };
@@ -112,55 +124,77 @@ static RecodeK make_recode_k(uint32_t c, uint32_t W) {
   }
   return k;
 }
-// signed digit of window w and the point sign; returns bucket index |d| (0 = skip)
-__device__ __forceinline__ uint32_t recode_digit(const Fr& mag, const RecodeK& K, uint32_t c, uint32_t w, bool& negative) {
+struct Recoded {
   uint32_t t[10];
+  bool sneg;
+};
+__device__ __forceinline__ Recoded recode_prepare(const Fr& mag, const RecodeK& K) {
+  Recoded r;
   uint32_t carry = 0;
-  bool sneg = (mag.v[7] >> 31) != 0;
+  r.sneg = (mag.v[7] >> 31) != 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     uint32_t m = i == 7 ? (mag.v[7] & 0x7fffffffu) : mag.v[i];
     uint32_t co;
-    t[i] = __builtin_addc(m, K.v[i], carry, &co);
+    r.t[i] = __builtin_addc(m, K.v[i], carry, &co);
     carry = co;
   }
-  t[8] = K.v[8] + carry;
-  t[9] = 0;
+  r.t[8] = K.v[8] + carry;
+  r.t[9] = 0;
+  return r;
+}
+// bucket index |d| of window w (0 = skip) and the sign of the point to add
+__device__ __forceinline__ uint32_t recode_digit(const Recoded& r, uint32_t c, uint32_t w, bool& negative) {
   uint32_t bit = c * w, li = bit >> 5, sh = bit & 31;
   uint32_t lo = 0, hi = 0;
 #pragma unroll
   for (int i = 0; i < 9; i++) {
-    lo = (li == (uint32_t)i) ? t[i] : lo;
-    hi = (li == (uint32_t)i) ? t[i + 1] : hi;
+    lo = (li == (uint32_t)i) ? r.t[i] : lo;
+    hi = (li == (uint32_t)i) ? r.t[i + 1] : hi;
   }
   uint64_t both = ((uint64_t)hi << 32) | lo;
   uint32_t dp = (uint32_t)(both >> sh) & ((1u << c) - 1u);
   int32_t d = (int32_t)dp - (int32_t)(1u << (c - 1));
-  negative = (d < 0) != sneg;
+  negative = (d < 0) != r.sneg;
   return (uint32_t)(d < 0 ? -d : d);
 }
 
-// ------------------------------------------------------------------ sort items of one (MSM, window) by bucket
-// grid (W, q); LDS: hist[B+1] + 256 scan slots.  idx[(q*W + w)*n + pos] = j | sign<<31, grouped by
-// bucket; off[(q*W + w)*(B+2) + b] = first position of bucket b (b = 0..B+1).
-__global__ void __launch_bounds__(256) k_msm_sort(const Fr* __restrict__ mags, uint32_t n, uint32_t W, uint32_t c, RecodeK K, const uint8_t* __restrict__ base_inf,
-                                                   uint32_t* __restrict__ idx, uint32_t* __restrict__ off) {
+// ------------------------------------------------------------------ job table
+struct MsmJob {          // one MSM: out = sum_j scalar_j * base_j
+  const G1A* table;      // [W][n] affine window table of the base set
+  const uint8_t* inf;    // [n] base-at-infinity flags
+  const Fr* mags;        // [n] prepared scalars (k_scalar_prep)
+  G1J* out;
+  uint32_t n, W;
+  uint64_t item_off;     // first slot of this job in the sorted-item array
+  uint64_t chunk_off;    // first slot of this job in the head/tail partial arrays
+};
+
+// ------------------------------------------------------------------ sort all (point, window) items of one MSM by bucket
+// grid: one workgroup per job; LDS: hist[B+2] + 1024 scan slots.
+// idx[item_off + pos] = j | w << 20 | sign << 31, grouped by bucket; off[job*(B+2) + b] = first pos of bucket b.
+__global__ void __launch_bounds__(1024) k_msm_sort(const MsmJob* __restrict__ jobs, uint32_t c, RecodeK K, uint32_t* __restrict__ idx, uint32_t* __restrict__ off) {
   extern __shared__ uint32_t lds[];
   const uint32_t B = 1u << (c - 1);
   uint32_t* hist = lds;            // B + 2
-  uint32_t* part = lds + (B + 2);  // 256
-  const uint32_t w = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;
-  const Fr* row = mags + (uint64_t)q * n;
-  for (uint32_t b = tid; b < B + 2; b += 256) hist[b] = 0;
+  uint32_t* part = lds + (B + 2);  // 1024
+  const MsmJob job = jobs[blockIdx.x];
+  const uint32_t tid = threadIdx.x, n = job.n, W = job.W;
+  for (uint32_t b = tid; b < B + 2; b += 1024) hist[b] = 0;
   __syncthreads();
-  for (uint32_t j = tid; j < n; j += 256) {
-    bool neg;
-    uint32_t b = base_inf[j] ? 0u : recode_digit(row[j], K, c, w, neg);
-    atomicAdd(&hist[b], 1u);
+  for (uint32_t j = tid; j < n; j += 1024) {
+    if (job.inf[j]) {
+      atomicAdd(&hist[0], W);
+      continue;
+    }
+    Recoded r = recode_prepare(job.mags[j], K);
+    for (uint32_t w = 0; w < W; w++) {
+      bool neg;
+      atomicAdd(&hist[recode_digit(r, c, w, neg)], 1u);
+    }
   }
   __syncthreads();
-  // exclusive scan of hist[0..B+1)
-  const uint32_t per = (B + 2 + 255) / 256;
+  const uint32_t per = (B + 2 + 1023) / 1024;
   uint32_t s = 0;
   for (uint32_t i = 0; i < per; i++) {
     uint32_t b = tid * per + i;
@@ -168,14 +202,14 @@ __global__ void __launch_bounds__(256) k_msm_sort(const Fr* __restrict__ mags, u
   }
   part[tid] = s;
   __syncthreads();
-  for (uint32_t d = 1; d < 256; d <<= 1) {
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
     uint32_t v = tid >= d ? part[tid - d] : 0;
     __syncthreads();
     part[tid] += v;
     __syncthreads();
   }
   uint32_t run = tid ? part[tid - 1] : 0;
-  uint32_t* o = off + ((uint64_t)q * W + w) * (B + 2);
+  uint32_t* o = off + (uint64_t)blockIdx.x * (B + 2);
   for (uint32_t i = 0; i < per; i++) {
     uint32_t b = tid * per + i;
     if (b < B + 2) {
@@ -186,39 +220,96 @@ __global__ void __launch_bounds__(256) k_msm_sort(const Fr* __restrict__ mags, u
     }
   }
   __syncthreads();
-  uint32_t* out = idx + ((uint64_t)q * W + w) * n;
-  for (uint32_t j = tid; j < n; j += 256) {
-    bool neg;
-    uint32_t b = base_inf[j] ? 0u : recode_digit(row[j], K, c, w, neg);
-    uint32_t pos = atomicAdd(&hist[b], 1u);
-    out[pos] = j | (neg ? 0x80000000u : 0u);
-  }
-}
-
-// one lane per (MSM q, bucket b in 1..B): mixed additions of every item of that bucket in all windows
-__global__ void __launch_bounds__(64) k_msm_accum(const G1A* __restrict__ table, uint32_t n, uint32_t W, uint32_t c, const uint32_t* __restrict__ idx,
-                                                   const uint32_t* __restrict__ off, G1J* __restrict__ buckets) {
-  const uint32_t B = 1u << (c - 1);
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x + 1;
-  const uint32_t q = blockIdx.y;
-  if (b > B) return;
-  G1J acc = g1_zero();
-  for (uint32_t w = 0; w < W; w++) {
-    const uint32_t* o = off + ((uint64_t)q * W + w) * (B + 2);
-    const uint32_t* items = idx + ((uint64_t)q * W + w) * n;
-    const G1A* tw = table + (uint64_t)w * n;
-    uint32_t p0 = o[b], p1 = o[b + 1];
-    for (uint32_t p = p0; p < p1; p++) {
-      uint32_t it = items[p];
-      G1A P = tw[it & 0x7fffffffu];
-      if (it >> 31) P.y = fp_neg(P.y);
-      acc = g1_add_mixed(acc, P);
+  uint32_t* out = idx + job.item_off;
+  for (uint32_t j = tid; j < n; j += 1024) {
+    if (job.inf[j]) continue;  // bucket-0 slots are never read
+    Recoded r = recode_prepare(job.mags[j], K);
+    for (uint32_t w = 0; w < W; w++) {
+      bool neg;
+      uint32_t b = recode_digit(r, c, w, neg);
+      if (b == 0) continue;
+      uint32_t pos = atomicAdd(&hist[b], 1u);
+      out[pos] = j | (w << 20) | (neg ? 0x80000000u : 0u);
     }
   }
-  buckets[(uint64_t)q * B + (b - 1)] = acc;
 }
 
-// U[q*c + i] = sum of buckets b (1..B) whose index has bit i set; grid (c, q), LDS tree
+// Each lane adds MSM_CHUNK consecutive items of the bucket-sorted list.  A bucket wholly inside the
+// chunk is stored to buckets[]; a bucket that started earlier goes to head[chunk], one that continues
+// later to tail[chunk].  grid (chunk blocks, jobs).
+__global__ void __launch_bounds__(64) k_msm_accum(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ off,
+                                                   G1J* __restrict__ buckets, G1J* __restrict__ head, G1J* __restrict__ tail) {
+  const uint32_t B = 1u << (c - 1);
+  const uint32_t q = blockIdx.y;
+  const MsmJob job = jobs[q];
+  const uint32_t* o = off + (uint64_t)q * (B + 2);
+  const uint32_t base = o[1], total = o[B + 1];
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t cs64 = (uint64_t)base + (uint64_t)t * MSM_CHUNK;
+  if (cs64 >= total) return;
+  const uint32_t cs = (uint32_t)cs64;
+  const uint32_t ce = cs + MSM_CHUNK < total ? cs + MSM_CHUNK : total;
+  // bucket containing item cs: largest b in [1, B] with o[b] <= cs
+  uint32_t lo = 1, hi = B;
+  while (lo < hi) {
+    uint32_t mid = (lo + hi + 1) >> 1;
+    if (o[mid] <= cs) lo = mid;
+    else hi = mid - 1;
+  }
+  uint32_t b = lo;
+  uint32_t bend = o[b + 1];
+  uint32_t run_start = cs;
+  const uint32_t* items = idx + job.item_off;
+  G1J acc = g1_zero();
+  G1J* bk = buckets + (uint64_t)q * B;
+  for (uint32_t p = cs; p < ce; p++) {
+    while (p >= bend) {  // bucket b ends here (possibly followed by empty buckets)
+      if (p > run_start) {
+        if (run_start == o[b]) bk[b - 1] = acc;                     // complete: started and ended inside this chunk
+        else head[job.chunk_off + t] = acc;                          // started in an earlier chunk
+        acc = g1_zero();
+      }
+      b++;
+      bend = o[b + 1];
+      run_start = p;
+    }
+    uint32_t it = items[p];
+    uint32_t j = it & 0xfffffu, w = (it >> 20) & 0x7ffu;
+    G1A P = job.table[(uint64_t)w * job.n + j];
+    if (it >> 31) P.y = fp_neg(P.y);
+    acc = g1_add_mixed(acc, P);
+  }
+  // last run of the chunk: [run_start, ce) of bucket b
+  bool starts = run_start == o[b], ends = ce == bend;
+  if (starts && ends) bk[b - 1] = acc;
+  else if (run_start == cs) head[job.chunk_off + t] = acc;  // reaches back to the chunk start (spans the whole chunk or came from before)
+  else tail[job.chunk_off + t] = acc;                        // starts inside, continues into the next chunk
+}
+
+// one lane per (job, bucket): empty -> infinity; split across chunks -> sum of the chunk partials
+__global__ void __launch_bounds__(64) k_msm_combine(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ off, G1J* __restrict__ buckets,
+                                                     const G1J* __restrict__ head, const G1J* __restrict__ tail) {
+  const uint32_t B = 1u << (c - 1);
+  const uint32_t q = blockIdx.y;
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x + 1;
+  if (b > B) return;
+  const MsmJob job = jobs[q];
+  const uint32_t* o = off + (uint64_t)q * (B + 2);
+  const uint32_t base = o[1], s = o[b], e = o[b + 1];
+  G1J* dst = buckets + (uint64_t)q * B + (b - 1);
+  if (s == e) {
+    *dst = g1_zero();
+    return;
+  }
+  const uint32_t t0 = (s - base) / MSM_CHUNK, t1 = (e - 1 - base) / MSM_CHUNK;
+  if (t0 == t1) return;  // complete inside one chunk: already stored by k_msm_accum
+  // chunk t0 holds the bucket's first piece: a tail unless the bucket starts exactly at the chunk start
+  G1J acc = ((s - base) == t0 * MSM_CHUNK) ? head[job.chunk_off + t0] : tail[job.chunk_off + t0];
+  for (uint32_t t = t0 + 1; t <= t1; t++) acc = g1_add(acc, head[job.chunk_off + t]);
+  *dst = acc;
+}
+
+// U[q*c + i] = sum of buckets b (1..B) whose index has bit i set; grid (c, jobs), LDS tree
 template <int T>
 __global__ void __launch_bounds__(T) k_msm_bits(const G1J* __restrict__ buckets, uint32_t c, G1J* __restrict__ U) {
   __shared__ G1J s[T];
@@ -237,64 +328,112 @@ __global__ void __launch_bounds__(T) k_msm_bits(const G1J* __restrict__ buckets,
   if (tid == 0) U[(uint64_t)q * c + i] = s[0];
 }
 
-// out[q] = sum_i 2^i U[q][i], emitted in canonical form (affine x, y, Z = ONE; infinity {0, ONE, 0})
-__global__ void __launch_bounds__(64) k_msm_horner(const G1J* __restrict__ U, uint32_t c, uint32_t q_total, G1J* __restrict__ out) {
+// out[q] = sum_i 2^i U[q][i]
+__global__ void __launch_bounds__(64) k_msm_horner(const MsmJob* __restrict__ jobs, const G1J* __restrict__ U, uint32_t c, uint32_t q_total) {
   uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= q_total) return;
   const G1J* u = U + (uint64_t)q * c;
   G1J acc = u[c - 1];
   for (int i = (int)c - 2; i >= 0; i--) acc = g1_add(g1_double(acc), u[i]);
-  G1J r = g1_zero();
-  if (!l_is_zero(acc.z)) {
-    Fp zi = fp_inv(acc.z), zi2 = fp_sqr(zi);
-    r.x = fp_mul(acc.x, zi2);
-    r.y = fp_mul(acc.y, fp_mul(zi2, zi));
-    r.z = fp_one();
-  }
-  out[q] = r;
+  *jobs[q].out = acc;
 }
 
-// q MSMs over the table's n bases; mags = prepared scalars (k_scalar_prep); W windows in use
-static int msm_run(zk_ctx* ctx, const G1Table& T, const Fr* mags, uint32_t q, uint32_t W, G1J* out) {
-  const uint32_t n = T.n, c = T.c;
-  if (W > T.W) return ctx->fail(ZK_ERR_ARG, "MSM: table has too few windows");
-  const uint32_t B = 1u << (c - 1);
-  RecodeK K = make_recode_k(c, W);
-  ZK_ALLOC(ctx, idx, uint32_t, (size_t)q * W * n);
-  ZK_ALLOC(ctx, off, uint32_t, (size_t)q * W * (B + 2));
-  ZK_ALLOC(ctx, buckets, G1J, (size_t)q * B);
-  ZK_ALLOC(ctx, U, G1J, (size_t)q * c);
-  size_t lds = (size_t)(B + 2 + 256) * 4;
-  uint64_t pairs = (uint64_t)q * n;
-  ZK_LAUNCH(ctx, "msm_sort", 32ull * pairs * W, k_msm_sort, dim3(W, q), dim3(256), lds, mags, n, W, c, K, (const uint8_t*)T.inf, idx.get(), off.get());
-  ZK_LAUNCH(ctx, "msm_accum", 100ull * pairs * W, k_msm_accum, dim3((B + 63) / 64, q), dim3(64), 0, (const G1A*)T.pts, n, W, c, (const uint32_t*)idx.get(),
-            (const uint32_t*)off.get(), buckets.get());
-  if (B >= 1024) ZK_LAUNCH(ctx, "msm_bucket_reduce", 144ull * q * B, k_msm_bits<256>, dim3(c, q), dim3(256), 0, (const G1J*)buckets.get(), c, U.get());
-  else ZK_LAUNCH(ctx, "msm_bucket_reduce", 144ull * q * B, k_msm_bits<64>, dim3(c, q), dim3(64), 0, (const G1J*)buckets.get(), c, U.get());
-  ZK_LAUNCH(ctx, "msm_horner", 144ull * q * c, k_msm_horner, dim3((q + 63) / 64), dim3(64), 0, (const G1J*)U.get(), c, q, out);
+// canonical form in place: affine x, y with Z = ONE; infinity as {0, ONE, 0}
+__global__ void __launch_bounds__(64) k_g1_canonicalise(G1J* __restrict__ pts, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  G1J p = pts[i];
+  G1J r = g1_zero();
+  if (!l_is_zero(p.z)) {
+    if (l_eq(p.z, fp_one())) return;
+    Fp zi = fp_inv(p.z), zi2 = fp_sqr(zi);
+    r.x = fp_mul(p.x, zi2);
+    r.y = fp_mul(p.y, fp_mul(zi2, zi));
+    r.z = fp_one();
+  }
+  pts[i] = r;
+}
+int g1_canonicalise_dev(zk_ctx* ctx, G1J* pts, uint32_t n) {
+  if (n) ZK_LAUNCH(ctx, "g1_canonicalise", 288ull * n, k_g1_canonicalise, dim3((n + 63) / 64), dim3(64), 0, pts, n);
   return ZK_OK;
 }
 
-static uint32_t pick_window(zk_ctx* ctx, uint32_t n, uint32_t bits) {
+uint32_t msm_pick_window(zk_ctx* ctx, uint32_t bits) {
   if (ctx->msm_window) return ctx->msm_window < 2 ? 2 : (ctx->msm_window > 13 ? 13 : ctx->msm_window);
-  if (bits <= 24) {
-    // short scalars (quantised weights): few windows, small bucket sets
-    uint32_t c = 7;
-    return c;
-  }
-  uint32_t lg = ceil_log2(n);
-  uint32_t c = lg + 1;
-  if (c < 8) c = 8;
-  if (c > 13) c = 13;
-  return c;
+  return bits <= 24 ? 7 : 10;  // short scalars (quantised weights): two 7-bit windows; full width: 26 x 10 bits
+}
+uint32_t msm_num_windows(uint32_t bits, uint32_t c) {
+  uint32_t W = (bits + 2 + c - 1) / c;  // +2 bits of head-room so mag + K never spills past the top window
+  return W ? W : 1;
 }
 
-// general entry: scalars are Fr values (Montgomery form if do_unmont, else raw canonical integers)
-int msm_batch_dev(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_unmont, bool probe_bits, G1J* out) {
+// run a list of MSM jobs that share the window width c (their tables were built with it)
+int msm_run_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs, uint32_t c) {
+  const uint32_t nj = (uint32_t)hjobs.size();
+  if (nj == 0) return ZK_OK;
+  const uint32_t B = 1u << (c - 1);
+  std::vector<MsmJob> jobs(nj);
+  uint64_t items = 0, chunks = 0, pairs = 0;
+  uint32_t max_chunks = 0, Wmax = 0;
+  for (uint32_t i = 0; i < nj; i++) {
+    const MsmJobHost& h = hjobs[i];
+    if (h.W > h.T->W || h.T->c != c) return ctx->fail(ZK_ERR_ARG, "MSM: job/table window mismatch");
+    MsmJob& j = jobs[i];
+    j.table = h.T->pts;
+    j.inf = h.T->inf;
+    j.mags = h.mags;
+    j.out = h.out;
+    j.n = h.T->n;
+    j.W = h.W;
+    j.item_off = items;
+    j.chunk_off = chunks;
+    uint64_t ni = (uint64_t)j.n * j.W;
+    uint32_t nc = (uint32_t)((ni + MSM_CHUNK - 1) / MSM_CHUNK);
+    items += ni;
+    chunks += nc;
+    pairs += j.n;
+    max_chunks = nc > max_chunks ? nc : max_chunks;
+    Wmax = j.W > Wmax ? j.W : Wmax;
+    if (j.n >= (1u << 20) || j.W >= (1u << 11)) return ctx->fail(ZK_ERR_ARG, "MSM: base set too large for the packed item format");
+  }
+  if (nj > 65535) return ctx->fail(ZK_ERR_ARG, "MSM: more than 65535 jobs in one batch");
+  RecodeK K = make_recode_k(c, Wmax);
+  ZK_ALLOC(ctx, djobs, MsmJob, nj);
+  {
+    // job table through the pinned staging ring (large batches: chunked synchronous copy)
+    size_t bytes = (size_t)nj * sizeof(MsmJob);
+    void* st = bytes <= (1u << 20) ? ctx->stage_put(jobs.data(), bytes) : nullptr;
+    if (st) ZK_HIP(ctx, hipMemcpyAsync(djobs.get(), st, bytes, hipMemcpyHostToDevice, ctx->stream));
+    else {
+      ZK_HIP(ctx, hipMemcpyAsync(djobs.get(), jobs.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+      ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+  }
+  ZK_ALLOC(ctx, idx, uint32_t, items);
+  ZK_ALLOC(ctx, off, uint32_t, (size_t)nj * (B + 2));
+  ZK_ALLOC(ctx, buckets, G1J, (size_t)nj * B);
+  ZK_ALLOC(ctx, head, G1J, chunks);
+  ZK_ALLOC(ctx, tail, G1J, chunks);
+  ZK_ALLOC(ctx, U, G1J, (size_t)nj * c);
+  size_t lds = (size_t)(B + 2 + 1024) * 4;
+  ZK_LAUNCH(ctx, "msm_sort", 32ull * pairs + 4ull * items, k_msm_sort, dim3(nj), dim3(1024), lds, (const MsmJob*)djobs.get(), c, K, idx.get(), off.get());
+  ZK_LAUNCH(ctx, "msm_accum", 100ull * items, k_msm_accum, dim3((max_chunks + 63) / 64, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, (const uint32_t*)idx.get(),
+            (const uint32_t*)off.get(), buckets.get(), head.get(), tail.get());
+  ZK_LAUNCH(ctx, "msm_combine", 144ull * nj * B, k_msm_combine, dim3((B + 63) / 64, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, (const uint32_t*)off.get(), buckets.get(),
+            (const G1J*)head.get(), (const G1J*)tail.get());
+  if (B >= 512) ZK_LAUNCH(ctx, "msm_bucket_reduce", 144ull * nj * B, k_msm_bits<256>, dim3(c, nj), dim3(256), 0, (const G1J*)buckets.get(), c, U.get());
+  else ZK_LAUNCH(ctx, "msm_bucket_reduce", 144ull * nj * B, k_msm_bits<64>, dim3(c, nj), dim3(64), 0, (const G1J*)buckets.get(), c, U.get());
+  ZK_LAUNCH(ctx, "msm_horner", 144ull * nj * c, k_msm_horner, dim3((nj + 63) / 64), dim3(64), 0, (const MsmJob*)djobs.get(), (const G1J*)U.get(), c, nj);
+  return ZK_OK;
+}
+
+// prepare q scalar rows over the generator set g and append them as jobs (out[i] receives MSM i)
+int msm_enqueue(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_unmont, bool probe_bits, G1J* out, MsmQueue* queue) {
   const uint32_t n = g->n;
   if (q == 0) return ZK_OK;
   uint64_t total = (uint64_t)q * n;
-  ZK_ALLOC(ctx, mags, Fr, total);
+  DBuf<Fr> mags;
+  if (!mags.alloc(ctx, total)) return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: MSM scalars");
   ZK_ALLOC(ctx, maxbits, uint32_t, 1);
   ZK_HIP(ctx, hipMemsetAsync(maxbits.get(), 0, 4, ctx->stream));
   ZK_LAUNCH(ctx, "msm_scalar_prep", 64ull * total, k_scalar_prep, dim3(stream_grid(total)), dim3(256), 0, scalars, mags.get(), total, do_unmont ? 1 : 0, maxbits.get());
@@ -303,12 +442,32 @@ int msm_batch_dev(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool d
     ZK_HIP(ctx, hipMemcpyAsync(&bits, maxbits.get(), 4, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
-  uint32_t c = pick_window(ctx, n, bits);
-  uint32_t W = (bits + 2 + c - 1) / c;  // +2 bits of head-room so mag + K never spills past the top window
-  if (W == 0) W = 1;
+  uint32_t c = msm_pick_window(ctx, bits);
+  uint32_t W = msm_num_windows(bits, c);
+  if (queue->c != 0 && queue->c != c) ZK_TRY(msm_flush(ctx, queue));  // one window width per batch
+  queue->c = c;
   const G1Table* T = nullptr;
   ZK_TRY(gens_table(ctx, g, c, W, &T));
-  return msm_run(ctx, *T, mags.get(), q, W, out);
+  for (uint32_t i = 0; i < q; i++) queue->jobs.push_back(MsmJobHost{T, mags.get() + (uint64_t)i * n, out + i, W});
+  queue->keep.push_back(std::move(mags));
+  return ZK_OK;
+}
+
+int msm_flush(zk_ctx* ctx, MsmQueue* queue) {
+  if (queue->jobs.empty()) return ZK_OK;
+  int rc = msm_run_jobs(ctx, queue->jobs, queue->c);
+  queue->jobs.clear();
+  queue->keep.clear();  // stream-ordered frees: safe behind the kernels just enqueued
+  queue->c = 0;
+  return rc;
+}
+
+// immediate (non-deferred) batch: q MSMs over g, canonical results in out
+int msm_batch_dev(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_unmont, bool probe_bits, G1J* out) {
+  MsmQueue queue;
+  ZK_TRY(msm_enqueue(ctx, g, scalars, q, do_unmont, probe_bits, out, &queue));
+  ZK_TRY(msm_flush(ctx, &queue));
+  return g1_canonicalise_dev(ctx, out, q);
 }
 
 // Commitment::commit, intended row semantics: out[row] = sum_j gens[j] * unmont(t[row*n + j])
@@ -332,7 +491,7 @@ __global__ void __launch_bounds__(256) k_mo_coef(const Fr* __restrict__ u, uint3
   C[idx] = acc;
 }
 // scal[(3r + e)*n + i] for rounds r < k, e in {T, T0, T1}; scal[3k*n + i] = unmont(C_k[i]).
-// S holds the folded scalar tensors back to back: S_r at offset n*(2 - 2^(1-r)) = 2n - (2n >> r).
+// S holds the folded scalar tensors back to back: S_r at offset 2n - (2n >> r).
 __global__ void __launch_bounds__(256) k_mo_scalars(const Fr* __restrict__ C, const Fr* __restrict__ S, uint32_t n, uint32_t k, Fr* __restrict__ scal) {
   uint64_t total = (uint64_t)(k + 1) * n;
   for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)gridDim.x * blockDim.x) {
@@ -352,12 +511,9 @@ __global__ void __launch_bounds__(256) k_mo_scalars(const Fr* __restrict__ C, co
   }
 }
 
-int me_open_flat_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d) {
+int me_open_flat_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d, MsmQueue* queue) {
   const uint32_t n = g->n;
-  if (k > 20 || n != (1u << k)) {
-    // the flattened form needs a full binary tree; odd sizes take the literal path
-    return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions (flattened me_open needs n == 2^k)");
-  }
+  if (k > 19 || n != (1u << k)) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions (flattened me_open needs n == 2^k)");
   // folded scalar tensors S_0 .. S_k (Fr only, tiny)
   ZK_ALLOC(ctx, S, Fr, 2ull * n + 2);
   ZK_HIP(ctx, hipMemcpyAsync(S.get(), t, (size_t)n * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
@@ -374,6 +530,7 @@ int me_open_flat_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32
   ZK_ALLOC(ctx, scal, Fr, (size_t)q * n);
   ZK_LAUNCH(ctx, "me_open_scalars", 32ull * q * n, k_mo_scalars, dim3(stream_grid((uint64_t)(k + 1) * n)), dim3(256), 0, (const Fr*)C.get(), (const Fr*)S.get(), n, k,
             scal.get());
+  if (queue) return msm_enqueue(ctx, g, scal.get(), q, /*do_unmont=*/false, /*probe_bits=*/false, proof_d, queue);
   return msm_batch_dev(ctx, g, scal.get(), q, /*do_unmont=*/false, /*probe_bits=*/false, proof_d);
 }
 
@@ -389,12 +546,13 @@ __global__ void __launch_bounds__(256) k_eq_scalars(const Fr* __restrict__ u, ui
   }
   out[j] = fr_unmont(acc);
 }
-int g1_me_msm_dev(zk_ctx* ctx, zk_gens* pts, const Fr* u_d, uint32_t k, G1J* dst_d) {
+int g1_me_msm_dev(zk_ctx* ctx, zk_gens* pts, const Fr* u_d, uint32_t k, G1J* dst_d, MsmQueue* queue) {
   const uint32_t m = pts->n;
   if (m == 0 || k > 31 || m > (1u << k)) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   if (k > 0 && m <= (1u << (k - 1))) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   ZK_ALLOC(ctx, scal, Fr, m);
   ZK_LAUNCH(ctx, "me_open_scalars", 32ull * m, k_eq_scalars, dim3((m + 255) / 256), dim3(256), 0, u_d, k, m, scal.get());
+  if (queue) return msm_enqueue(ctx, pts, scal.get(), 1, /*do_unmont=*/false, /*probe_bits=*/false, dst_d, queue);
   return msm_batch_dev(ctx, pts, scal.get(), 1, /*do_unmont=*/false, /*probe_bits=*/false, dst_d);
 }
 
