@@ -136,11 +136,7 @@ class Workload:
                 self.relus[i].prove(self.Z[i], self.A[i], ch, self.tr)
 
 
-def lanes_to_fr(lanes):
-    v = 0
-    for j, x in enumerate(lanes):
-        v += int(x) << (32 * j)
-    return v % R_MOD
+from zkdl_amd.dist import lanes_to_fr  # noqa: E402
 
 
 def cpu_baseline(zk, wl, max_seconds=60.0):

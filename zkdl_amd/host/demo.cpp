@@ -1,0 +1,123 @@
+// zkdl_amd/host/demo.cpp -- the reference driver (demo.cu) on the MI355X library.
+//   ./demo traced_model.pt sample_input.pt [--seed S]
+// Same CLI, same inputs (TorchScript nn.Sequential of bias-free Linear + ReLU; a tensor saved as
+// parameter "0" of a scripted empty module, model.py:4-8), same outputs: demo.out (Y_hat, one
+// 0x%064x per line, demo.cu:119-122) and the three stdout lines (demo.cu:92,140-141).
+// Differences: tensors may live on the CPU (the reference hard-fails, demo.cu:79,114); the contiguous
+// weight tensor is kept alive while its pointer is used (the reference dangles, demo.cu:78).
+#include <torch/script.h>
+#include <torch/torch.h>
+
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "zkdl.hpp"
+
+using namespace std;
+
+// device copy of a float tensor's contents (zkFC::from_float_gpu_ptr wants a device pointer)
+struct DeviceFloats {
+  float* p = nullptr;
+  explicit DeviceFloats(const torch::Tensor& t) {
+    auto c = t.to(torch::kCPU).to(torch::kFloat32).contiguous();
+    void* d = nullptr;
+    zkdl::check(zk_malloc(zkdl::ctx(), (size_t)c.numel() * sizeof(float), &d));
+    zkdl::check(zk_memcpy_h2d(zkdl::ctx(), d, c.data_ptr<float>(), (size_t)c.numel() * sizeof(float)));
+    p = static_cast<float*>(d);
+  }
+  ~DeviceFloats() { zk_free(zkdl::ctx_slot(), p); }
+};
+
+FrTensor fcnn_inference(const FrTensor& X, const vector<zkFC>& fcs, vector<zkReLU>& relus, vector<FrTensor>& Z_vec, vector<FrTensor>& A_vec) {   // demo.cu:23-38
+  if (fcs.size() != relus.size() + 1) throw std::runtime_error("Incompatible number of layers");
+  uint num_layer = fcs.size();
+  for (uint i = 0; i < num_layer - 1; ++i) {
+    const auto& A = (i == 0) ? X : A_vec[i - 1];
+    Z_vec.push_back(fcs[i](A));
+    A_vec.push_back(relus[i](Z_vec[i]));
+  }
+  return fcs[num_layer - 1](A_vec[num_layer - 2]);
+}
+
+torch::Tensor load_tensor(const string& path) {   // demo.cu:40-46
+  torch::Tensor tensor;
+  torch::load(tensor, path);
+  return tensor;
+}
+
+vector<zkFC> load_model(const string& model_path, vector<unique_ptr<Commitment>>& generators) {   // demo.cu:48-95
+  vector<zkFC> fcs;
+  torch::jit::script::Module m;
+  try {
+    m = torch::jit::load(model_path, torch::kCPU);
+  } catch (const c10::Error& e) {
+    std::cerr << "Error loading the model\n";
+    exit(-1);
+  }
+  uint parameter_count = 0;
+  for (int i = 0;; ++i) {
+    if (!m.hasattr(to_string(i))) break;
+    if (!m.attr(to_string(i)).toModule().hasattr("weight")) continue;
+    auto weight_tensor = m.attr(to_string(i)).toModule().attr("weight").toTensor().t();
+    int in_dim = weight_tensor.sizes()[0], out_dim = weight_tensor.sizes()[1];
+    parameter_count += in_dim * out_dim;
+    DeviceFloats w(weight_tensor);
+    generators.emplace_back(new Commitment(1U << ((ceilLog2(in_dim * out_dim) + 1) / 2), G1Jacobian_generator));   // demo.cu:81
+    *generators.back() *= FrTensor::random(generators.back()->size);                                               // demo.cu:82
+    fcs.push_back(zkFC::from_float_gpu_ptr(in_dim, out_dim, w.p, *generators.back()));
+    if (fcs.size() > 1 && fcs[fcs.size() - 2].outputSize != fcs[fcs.size() - 1].inputSize) throw std::runtime_error("Incompatible layer sizes");
+  }
+  cout << "Total number of parameters: " << parameter_count << endl;
+  return fcs;
+}
+
+int main(int argc, char* argv[]) {
+  if (argc < 3) {
+    cerr << "usage: demo traced_model.pt sample_input.pt [--seed S]\n";
+    return 2;
+  }
+  for (int i = 3; i + 1 < argc; i++)
+    if (string(argv[i]) == "--seed") zkdl::seed(strtoull(argv[i + 1], nullptr, 0));
+  vector<unique_ptr<Commitment>> generators;
+  vector<zkFC> fcs = load_model(argv[1], generators);
+  vector<zkReLU> relus(fcs.size() - 1);
+  vector<FrTensor> Z_vec, A_vec;
+  Z_vec.reserve(fcs.size());
+  A_vec.reserve(fcs.size());
+
+  torch::Tensor sample_input = load_tensor(argv[2]);
+  int batch_size = sample_input.size(0), input_dim = sample_input.size(1);
+  DeviceFloats xin(sample_input);
+  auto X = zkFC::load_float_gpu_input(batch_size, input_dim, xin.p);
+
+  auto Y_hat = fcnn_inference(X.mont(), fcs, relus, Z_vec, A_vec).unmont();   // demo.cu:119
+  ofstream outfile("demo.out");
+  outfile << Y_hat << endl;
+  outfile.close();
+
+  Timer timer;
+  zk_ctx_sync(zkdl::ctx());
+  timer.start();
+  auto num_layer = fcs.size();
+  fcs[num_layer - 1].prove(A_vec[num_layer - 2], Y_hat, *generators[num_layer - 1]);
+  for (int i = num_layer - 2; i >= 0; --i) {
+    relus[i].prove(Z_vec[i], A_vec[i]);
+    FrTensor& A_ = (i > 0) ? A_vec[i - 1] : X;
+    fcs[i].prove(A_, Z_vec[i], *generators[i]);
+  }
+  zk_transcript_flush(zkdl::transcript());   // the deferred MSM batch belongs to the timed region
+  zk_ctx_sync(zkdl::ctx());
+  timer.stop();
+
+  size_t n_fr = 0, n_g1 = 0;
+  zk_transcript_counts(zkdl::transcript(), &n_fr, &n_g1);
+  Fr_t digest;
+  zk_transcript_digest(zkdl::transcript(), &digest);
+  cout << "Proof time: " << timer.getTotalTime() / batch_size << " seconds per data point." << endl;
+  cout << "Current HIP status: " << 0 << endl;
+  cout << "Transcript: " << n_fr << " Fr + " << n_g1 << " G1 values, digest " << digest << endl;
+  return 0;
+}

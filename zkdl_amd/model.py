@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Counterpart of the reference's model.py: emit traced_model.pt / sample_input.pt /
+sample_output.pt for `zkdl_amd/host/demo` (same file formats: a traced nn.Sequential of bias-free
+Linear + ReLU whose children are named "0","1",...; a tensor stored as parameter "0" of a scripted
+empty module, model.py:4-8).  Unlike the reference it takes a seed and a --dims/--batch override, so
+tiny fixtures and the full-size synthetic configs come from the same code.
+
+    python -m zkdl_amd.model --out-dir /tmp/m                      # the 18M-parameter MLP, batch 256
+    python -m zkdl_amd.model --dims 6,5,4 --batch 3 --seed 7 --out-dir /tmp/m
+"""
+import argparse
+import os
+
+import torch
+import torch.nn as nn
+
+DEFAULT_DIMS = [784, 1000, 1773, 1773, 1773, 1773, 1773, 1124, 1000]   # model.py:14-30
+
+
+def save_tensor(t, fn):
+    m = nn.Module()
+    m.register_parameter("0", nn.Parameter(t))
+    torch.jit.script(m).save(fn)
+
+
+def build(dims, seed):
+    torch.manual_seed(seed)
+    layers = []
+    for i, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
+        layers.append(nn.Linear(a, b, bias=False))
+        if i + 2 < len(dims):
+            layers.append(nn.ReLU())
+    return nn.Sequential(*layers).eval()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dims", default=",".join(map(str, DEFAULT_DIMS)))
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--out-dir", default=".")
+    args = ap.parse_args()
+    dims = [int(x) for x in args.dims.split(",")]
+    os.makedirs(args.out_dir, exist_ok=True)
+    model = build(dims, args.seed)
+    x = torch.randn(args.batch, dims[0])
+    with torch.no_grad():
+        y = model(x)
+    save_tensor(x, os.path.join(args.out_dir, "sample_input.pt"))
+    save_tensor(y, os.path.join(args.out_dir, "sample_output.pt"))
+    torch.jit.trace(model, x[:1]).save(os.path.join(args.out_dir, "traced_model.pt"))
+    print("wrote traced_model.pt, sample_input.pt, sample_output.pt to", args.out_dir)
+
+
+if __name__ == "__main__":
+    main()
