@@ -240,6 +240,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    t_enq = time.perf_counter() - t0          # host time to enqueue K steps (no device wait inside)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -277,7 +278,7 @@ def main():
            "data": "synthetic",
            "config": {"workload": args.workload, "dims": dims, "batch_per_gpu": batch, "parallelism": "independent proofs per rank, RCCL all-reduce of the aggregate",
                       "msm": args.msm},
-           "ms_per_proof": ms_per_step, "aggregate_fr": hex(aggregate), "setup": wl.info, "roofline": roofline, "kernels": kernels,
+           "ms_per_proof": ms_per_step, "host_enqueue_ms_per_step": t_enq * 1e3 / max(args.steps, 1), "aggregate_fr": hex(aggregate), "setup": wl.info, "roofline": roofline, "kernels": kernels,
            "g1_msm_mops_commit": wl.info["commit_mops"]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(zk, wl)

@@ -383,3 +383,29 @@ def test_mlp_prove_pippenger_matches_oracle(zk, oracle, dims, batch):
         ga, gi = affine_of(oracle, a)
         wa, wi = affine_of(oracle, b)
         assert eq(ga, wa) and eq(gi, wi)
+
+
+# ------------------------------------------------------------------ packed ReLU proofs vs the one-Fr-per-bit path
+@pytest.mark.parametrize("n", [1, 5, 64, 300, 4096])
+def test_relu_prove_packed_equals_unpacked_and_oracle(zk, oracle, rng, n):
+    from zkdl_amd.capi import ReLU, Transcript
+    import bigint_model as bm
+    vals = rng.integers(-(1 << 46), 1 << 46, size=n).tolist()
+    vals[0] = (1 << 47) - 1
+    X = np.stack([bm.fr_to_mont(v % bm.R_MOD) for v in vals])
+    relu = ReLU(zk)
+    dX = zk.upload(X)
+    A = relu.forward(dX)
+    k = zk.ceil_log2(n)
+    ch = [rand_fr(rng, m) for m in (k + 5, k + 5, k + 4, k + 4, k, k, k)]
+    out = {}
+    for packed in (1, 0):
+        zk.set_flag("relu_packed", packed)
+        tr = Transcript(zk)
+        relu.prove(dX, A, ch, tr)
+        out[packed], _ = tr.read()
+    zk.set_flag("relu_packed", 1)
+    assert eq(out[1], out[0])
+    if n <= 300:
+        wA, wsign, wmag, wrem = oracle.relu_forward(X)
+        assert eq(out[1], oracle.relu_prove(X, wA, wsign, wmag, wrem, *ch))

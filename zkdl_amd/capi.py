@@ -29,7 +29,7 @@ zk_fr_add_scalar zk_fr_sub_scalar zk_fr_mul_scalar zk_fr_mont zk_fr_unmont zk_fr
 zk_fr_partial_me zk_fr_split zk_sumcheck_ip zk_sumcheck_hadamard zk_sumcheck_binary zk_g1_fill zk_g1a_fill
 zk_g1_from_affine zk_g1_neg zk_g1a_neg zk_g1_add zk_g1_sub zk_g1_madd zk_g1_msub zk_g1_add_bcast zk_g1_sub_bcast
 zk_g1_madd_bcast zk_g1_msub_bcast zk_g1_sum zk_g1_mul zk_g1_mul_bcast zk_g1_me zk_g1_to_affine zk_set_msm_mode
-zk_set_msm_window zk_gens_create zk_gens_destroy zk_gens_size zk_gens_points zk_commit zk_me_open zk_open zk_msm_batch zk_float_to_fr zk_fc_create zk_fc_from_float zk_fc_destroy zk_fc_in
+zk_set_msm_window zk_set_flag zk_gens_create zk_gens_destroy zk_gens_size zk_gens_points zk_commit zk_me_open zk_open zk_msm_batch zk_float_to_fr zk_fc_create zk_fc_from_float zk_fc_destroy zk_fc_in
 zk_fc_out zk_fc_com_size zk_fc_weights zk_fc_com zk_fc_load_input zk_fc_forward zk_fc_prove zk_relu_create
 zk_relu_destroy zk_relu_forward zk_relu_sign zk_relu_mag_bin zk_relu_rem_bin zk_relu_prove zk_transcript_create
 zk_transcript_destroy zk_transcript_reset zk_transcript_flush zk_transcript_counts zk_transcript_read zk_transcript_read_affine
@@ -68,7 +68,7 @@ def _header_prototypes():
             for a in args.split(","):
                 a = a.strip()
                 if "*" in a:
-                    argtypes.append(_vp)
+                    argtypes.append(ctypes.c_char_p if "char" in a and "**" not in a else _vp)
                 else:
                     base = a.replace("const", "").split()[0]
                     argtypes.append(_CTYPE[base])
@@ -388,6 +388,9 @@ class Zk:
     # ---- commitment
     def set_msm_mode(self, mode):
         self._chk(self.lib.zk_set_msm_mode(self.ctx, int(mode)))
+
+    def set_flag(self, name, value):
+        self._chk(self.lib.zk_set_flag(self.ctx, name.encode(), int(value)))
 
     def set_msm_window(self, bits):
         self._chk(self.lib.zk_set_msm_window(self.ctx, _u32(bits)))

@@ -86,12 +86,6 @@ int zk_ctx_create(int device, zk_ctx** out) {
     delete ctx;
     return ZK_ERR_ALLOC;
   }
-  // keep freed temporaries cached in the stream-ordered pool (288 GB of HBM: never trim)
-  hipMemPool_t pool;
-  if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
-    uint64_t thr = UINT64_MAX;
-    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
-  }
   *out = ctx;
   return ZK_OK;
 }
@@ -104,6 +98,7 @@ int zk_ctx_destroy(zk_ctx* ctx) {
   (void)hipEventDestroy(ctx->t0);
   (void)hipEventDestroy(ctx->t1);
   (void)hipHostFree(ctx->stage);
+  ctx->pool_destroy();
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return ZK_OK;
@@ -119,42 +114,32 @@ void* zk_ctx_stream(zk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 int zk_malloc(zk_ctx* ctx, size_t bytes, void** out_d) {
   CHECK_CTX(ctx);
   CHECK_HOST(ctx, out_d);
-  *out_d = nullptr;
-  if (hipMallocAsync(out_d, bytes ? bytes : 16, ctx->stream) != hipSuccess) {
-    (void)hipGetLastError();
-    return ctx->fail(ZK_ERR_ALLOC, "device allocation of " + std::to_string(bytes) + " bytes failed");
-  }
+  *out_d = ctx->pool_alloc(bytes ? bytes : 16);
+  if (!*out_d) return ctx->fail(ZK_ERR_ALLOC, "device allocation of " + std::to_string(bytes) + " bytes failed");
   return ZK_OK;
 }
 int zk_free(zk_ctx* ctx, void* p) {
   CHECK_CTX(ctx);
-  if (p) ZK_HIP(ctx, hipFreeAsync(p, ctx->stream));
+  ctx->pool_release(p);
   return ZK_OK;
 }
 int zk_memcpy_h2d(zk_ctx* ctx, void* dst, const void* src, size_t bytes) {
   CHECK_CTX(ctx);
   if (!bytes) return ZK_OK;
-  // pageable source: make the copy complete before returning so the caller may free src
-  ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return ZK_OK;
+  return host_to_dev(ctx, dst, src, bytes);
 }
 int zk_memcpy_d2h(zk_ctx* ctx, void* dst, const void* src, size_t bytes) {
   CHECK_CTX(ctx);
   if (!bytes) return ZK_OK;
-  ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return ZK_OK;
+  return dev_to_host(ctx, dst, src, bytes);
 }
 int zk_memcpy_d2d(zk_ctx* ctx, void* dst, const void* src, size_t bytes) {
   CHECK_CTX(ctx);
-  if (bytes) ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-  return ZK_OK;
+  return dev_copy(ctx, dst, src, bytes);
 }
 int zk_memset_zero(zk_ctx* ctx, void* dst, size_t bytes) {
   CHECK_CTX(ctx);
-  if (bytes) ZK_HIP(ctx, hipMemsetAsync(dst, 0, bytes, ctx->stream));
-  return ZK_OK;
+  return dev_zero(ctx, dst, bytes);
 }
 
 int zk_timer_start(zk_ctx* ctx) {
@@ -452,6 +437,13 @@ int zk_set_msm_mode(zk_ctx* ctx, int mode) {
   ctx->msm_mode = mode;
   return ZK_OK;
 }
+int zk_set_flag(zk_ctx* ctx, const char* name, int value) {
+  CHECK_CTX(ctx);
+  CHECK_HOST(ctx, name);
+  if (!strcmp(name, "relu_packed")) ctx->relu_packed = value != 0;
+  else return ctx->fail(ZK_ERR_ARG, std::string("unknown flag: ") + name);
+  return ZK_OK;
+}
 int zk_set_msm_window(zk_ctx* ctx, uint32_t w) {
   CHECK_CTX(ctx);
   if (w > 16) return ctx->fail(ZK_ERR_ARG, "MSM window must be 0 (auto) or 1..16 bits");
@@ -546,7 +538,7 @@ int zk_fc_from_float(zk_ctx* ctx, uint32_t in, uint32_t out, const float* w, zk_
 }
 int zk_fc_destroy(zk_fc* fc) {
   if (!fc) return ZK_ERR_ARG;
-  (void)hipFree(fc->weights);
+  if (fc->ctx) dev_free(fc->ctx, fc->weights);
   gens_destroy(fc->com);
   delete fc;
   return ZK_OK;
@@ -585,7 +577,6 @@ int zk_relu_create(zk_ctx* ctx, zk_relu** out) {
 }
 int zk_relu_destroy(zk_relu* relu) {
   if (!relu) return ZK_ERR_ARG;
-  if (relu->ctx) (void)hipStreamSynchronize(relu->ctx->stream);
   relu->free_all();
   delete relu;
   return ZK_OK;
@@ -618,8 +609,8 @@ int zk_transcript_create(zk_ctx* ctx, zk_transcript** out) {
 int zk_transcript_destroy(zk_transcript* tr) {
   if (!tr) return ZK_ERR_ARG;
   (void)tr->flush();
-  if (tr->fr_d) (void)hipFreeAsync(tr->fr_d, tr->ctx->stream);
-  if (tr->g1_d) (void)hipFreeAsync(tr->g1_d, tr->ctx->stream);
+  dev_free(tr->ctx, tr->fr_d);
+  dev_free(tr->ctx, tr->g1_d);
   delete tr;
   return ZK_OK;
 }

@@ -23,22 +23,21 @@ int gens_create(zk_ctx* ctx, const G1J* gens_d, uint32_t n, bool copy, zk_gens**
   zk_gens* g = new zk_gens();
   g->ctx = ctx;
   g->n = n;
-  if (hipMalloc((void**)&g->pts, (size_t)n * sizeof(G1J)) != hipSuccess) {
+  if (dev_alloc(ctx, (void**)&g->pts, (size_t)n * sizeof(G1J)) != hipSuccess) {
     delete g;
     return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: generators");
   }
-  if (copy) ZK_HIP(ctx, hipMemcpyAsync(g->pts, gens_d, (size_t)n * sizeof(G1J), hipMemcpyDeviceToDevice, ctx->stream));
+  if (copy) ZK_TRY(dev_copy(ctx, g->pts, gens_d, (size_t)n * sizeof(G1J)));
   *out = g;
   return ZK_OK;
 }
 void gens_destroy(zk_gens* g) {
   if (!g) return;
-  if (g->ctx) (void)hipStreamSynchronize(g->ctx->stream);
   for (auto& kv : g->tables) {
-    (void)hipFree(kv.second.pts);
-    (void)hipFree(kv.second.inf);
+    dev_free(g->ctx, kv.second.pts);
+    dev_free(g->ctx, kv.second.inf);
   }
-  (void)hipFree(g->pts);
+  dev_free(g->ctx, g->pts);
   delete g;
 }
 
@@ -111,8 +110,8 @@ static int me_open_literal_dev(zk_ctx* ctx, const Fr* t, const G1J* gens, uint32
     g = go;
     sz = ns;
   }
-  ZK_HIP(ctx, hipMemcpyAsync(proof_d + 3 * k, g, sizeof(G1J), hipMemcpyDeviceToDevice, ctx->stream));  // generators(0)
-  ZK_HIP(ctx, hipMemcpyAsync(ret_d, s, sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));            // t(0)
+  ZK_TRY(dev_copy(ctx, proof_d + 3 * k, g, sizeof(G1J)));  // generators(0)
+  ZK_TRY(dev_copy(ctx, ret_d, s, sizeof(Fr)));            // t(0)
   return ZK_OK;
 }
 

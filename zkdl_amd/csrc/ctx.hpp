@@ -2,9 +2,8 @@
 //
 // The reference allocates with cudaMalloc/cudaFree around every operator and calls
 // cudaDeviceSynchronize() after every launch (fr-tensor.cu:92-127).  Here every operation is
-// enqueued on one HIP stream, temporaries come from the stream-ordered pool
-// (hipMallocAsync/hipFreeAsync, release threshold = keep everything), and the host only waits
-// when a value has to cross to it.
+// enqueued on one HIP stream, all device memory comes from the context's caching allocator (no
+// driver call in steady state), and the host only waits when a value has to cross to it.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -12,6 +11,7 @@
 
 #include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/zkdl_amd.h"
@@ -35,6 +35,7 @@ struct zk_ctx {
   // MSM configuration
   int msm_mode = ZK_MSM_PIPPENGER;
   uint32_t msm_window = 0;
+  bool relu_packed = true;  // ReLU aux proofs from packed bits (relu_packed.hip) instead of one-Fr-per-bit tensors
   // timing
   hipEvent_t t0 = nullptr, t1 = nullptr;
   bool prof_on = false;
@@ -51,6 +52,65 @@ struct zk_ctx {
   uint8_t* stage = nullptr;
   size_t stage_cap = 0, stage_off = 0;
   void* stage_put(const void* src, size_t bytes);  // returns pinned address holding a copy
+
+  // ---- device memory: a size-class caching allocator over plain hipMalloc blocks.
+  // All work of a context is enqueued on ONE stream, so a block may be handed out again as soon as it
+  // is released: every later use is ordered behind every earlier use.  Blocks are never returned to
+  // the driver before the context dies (288 GB of HBM), so steady-state proving makes no allocator
+  // calls into the runtime at all.  (hipMallocAsync/hipFreeAsync were dropped: on ROCm 7.2 the
+  // stream-ordered pool was observed to hand a still-live block out a second time.)
+  std::unordered_map<void*, size_t> pool_size;               // every block ever allocated -> class size
+  std::unordered_map<void*, bool> pool_idle;                 // double-release guard
+  uint64_t pool_double_release = 0;
+  std::map<size_t, std::vector<void*>> pool_free_lists;      // class size -> idle blocks
+  size_t pool_bytes = 0;
+  static size_t pool_class(size_t bytes) {
+    if (bytes < 256) return 256;
+    // 4 classes per octave: waste <= 19 %
+    size_t p = 256;
+    while (p < bytes) p <<= 1;          // smallest power of two >= bytes
+    size_t q = p >> 3;                  // eighth of it
+    for (size_t c = (p >> 1) + q; c < p; c += q)
+      if (c >= bytes) return c;
+    return p;
+  }
+  void* pool_alloc(size_t bytes) {
+    size_t cls = pool_class(bytes);
+    auto& fl = pool_free_lists[cls];
+    if (!fl.empty()) {
+      void* p = fl.back();
+      fl.pop_back();
+      pool_idle[p] = false;
+      return p;
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, cls) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    pool_size[p] = cls;
+    pool_idle[p] = false;
+    pool_bytes += cls;
+    return p;
+  }
+  void pool_release(void* p) {
+    if (!p) return;
+    auto it = pool_size.find(p);
+    if (it == pool_size.end()) return;  // not ours (never happens for library-made pointers)
+    bool& idle = pool_idle[p];
+    if (idle) {  // releasing twice would hand one block to two owners: refuse and remember
+      ++pool_double_release;
+      last_error = "internal error: device block released twice";
+      return;
+    }
+    idle = true;
+    pool_free_lists[it->second].push_back(p);
+  }
+  void pool_destroy() {
+    for (auto& kv : pool_size) (void)hipFree(kv.first);
+    pool_size.clear();
+    pool_free_lists.clear();
+  }
 
   int fail(int code, const std::string& msg) {
     last_error = msg;
@@ -106,13 +166,26 @@ struct ProfScope {
 };
 
 // launch on the context's stream; `bytes` = algorithmic HBM bytes of this launch
-#define ZK_LAUNCH(ctx, name, bytes, kernel, grid, block, shmem, ...)                   \
-  do {                                                                                 \
-    zk::ProfScope _ps((ctx), (name), (uint64_t)(bytes));                               \
-    hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);        \
+#define ZK_LAUNCH(ctx, name, bytes, kernel, grid, block, shmem, ...)                                     \
+  do {                                                                                                   \
+    {                                                                                                    \
+      zk::ProfScope _ps((ctx), (name), (uint64_t)(bytes));                                               \
+      hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);                        \
+    }                                                                                                    \
+    hipError_t _le = hipGetLastError();                                                                  \
+    if (_le != hipSuccess) return (ctx)->fail(ZK_ERR_DEVICE, std::string("launch of ") + (name) + " failed: " + hipGetErrorString(_le)); \
   } while (0)
 
-// Stream-ordered temporary device buffer.
+// Persistent device buffers and temporaries both come from the context's caching allocator.
+inline hipError_t dev_alloc(zk_ctx* ctx, void** p, size_t bytes) {
+  *p = ctx->pool_alloc(bytes);
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+inline void dev_free(zk_ctx* ctx, void* p) {
+  if (ctx) ctx->pool_release(p);
+}
+
+// Temporary device buffer (released back to the context's allocator; reuse is stream-ordered).
 template <class T>
 struct DBuf {
   zk_ctx* ctx = nullptr;
@@ -134,15 +207,11 @@ struct DBuf {
     ctx = c;
     n = count;
     size_t bytes = (count ? count : 1) * sizeof(T);
-    if (hipMallocAsync((void**)&p, bytes, c->stream) != hipSuccess) {
-      p = nullptr;
-      (void)hipGetLastError();
-      return false;
-    }
-    return true;
+    p = static_cast<T*>(c->pool_alloc(bytes));
+    return p != nullptr;
   }
   void release() {
-    if (p) (void)hipFreeAsync(p, ctx->stream);
+    if (p) ctx->pool_release(p);
     p = nullptr;
   }
   ~DBuf() { release(); }
@@ -193,6 +262,12 @@ ZK_HD Fr rng_fr(uint64_t seed, uint64_t draw, uint64_t idx) {
   return r;
 }
 
+// memops.hip
+int dev_copy(zk_ctx* ctx, void* dst, const void* src, size_t bytes);
+int dev_zero(zk_ctx* ctx, void* dst, size_t bytes);
+int host_to_dev(zk_ctx* ctx, void* dst, const void* src, size_t bytes);
+int dev_to_host(zk_ctx* ctx, void* dst, const void* src, size_t bytes);
+
 // ---- internal (device-pointer) entry points shared between translation units
 // fr_kernels.hip
 int fr_binary(zk_ctx* ctx, int op, const Fr* a, const Fr* b, Fr* out, uint32_t n);
@@ -221,7 +296,7 @@ inline int upload_fr(zk_ctx* ctx, DBuf<Fr>& buf, const zk_fr* h, uint32_t k) {
   if (k) {
     void* st = ctx->stage_put(h, (size_t)k * sizeof(Fr));
     if (!st) return ctx->fail(ZK_ERR_ALLOC, "pinned staging exhausted");
-    ZK_HIP(ctx, hipMemcpyAsync(buf.get(), st, (size_t)k * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    ZK_TRY(dev_copy(ctx, buf.get(), st, (size_t)k * sizeof(Fr)));  // kernel reading the pinned staging ring
   }
   return ZK_OK;
 }

@@ -84,8 +84,7 @@ __global__ void __launch_bounds__(256) k_fr_sum(const Fr* __restrict__ a, uint32
 }
 int fr_sum_dev(zk_ctx* ctx, const Fr* a, uint32_t n, Fr* dst_d) {
   if (n == 0) {
-    ZK_HIP(ctx, hipMemsetAsync(dst_d, 0, sizeof(Fr), ctx->stream));
-    return ZK_OK;
+    return dev_zero(ctx, dst_d, sizeof(Fr));
   }
   uint32_t g = stream_grid(n, 256, 1024);
   if (g == 1) {
@@ -168,8 +167,7 @@ int fr_me_dev(zk_ctx* ctx, const Fr* t, uint32_t n, const Fr* u_d, uint32_t k, F
   if (n == 0 || k > 31) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   if (n <= ((1u << k) / 2) || n > (1u << k)) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   if (k == 0) {
-    ZK_HIP(ctx, hipMemcpyAsync(dst_d, t, sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
-    return ZK_OK;
+    return dev_copy(ctx, dst_d, t, sizeof(Fr));
   }
   const Fr* cur = t;
   uint32_t cur_n = n, kk = k, off = 0;
@@ -205,8 +203,7 @@ uint32_t fr_partial_me_size(uint32_t n, uint32_t k, uint32_t window) {
 int fr_partial_me_dev(zk_ctx* ctx, const Fr* t, uint32_t n, const Fr* u_d, uint32_t k, uint32_t W, Fr* out_d) {
   if (W == 0 || k > 31) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   if (k == 0) {
-    if (n) ZK_HIP(ctx, hipMemcpyAsync(out_d, t, (size_t)n * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
-    return ZK_OK;
+    return dev_copy(ctx, out_d, t, (size_t)n * sizeof(Fr));
   }
   if ((uint64_t)n <= (uint64_t)W * (1ull << (k - 1))) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   const Fr* cur = t;

@@ -139,8 +139,7 @@ int g1_sum_dev(zk_ctx* ctx, const G1J* a, uint32_t n, G1J* dst_d) {
     return g1_fill_dev(ctx, dst_d, 1, z);
   }
   if (n == 1) {
-    ZK_HIP(ctx, hipMemcpyAsync(dst_d, a, sizeof(G1J), hipMemcpyDeviceToDevice, ctx->stream));
-    return ZK_OK;
+    return dev_copy(ctx, dst_d, a, sizeof(G1J));
   }
   uint32_t first = (n + 63) / 64;
   ZK_ALLOC(ctx, buf0, G1J, first);
@@ -189,8 +188,7 @@ int g1_me_dev(zk_ctx* ctx, const G1J* t, uint32_t n, const Fr* u_d, uint32_t k, 
   if (n == 0 || k > 31 || n > (1u << k)) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   if (k > 0 && n <= (1u << (k - 1))) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   if (k == 0) {
-    ZK_HIP(ctx, hipMemcpyAsync(dst_d, t, sizeof(G1J), hipMemcpyDeviceToDevice, ctx->stream));
-    return ZK_OK;
+    return dev_copy(ctx, dst_d, t, sizeof(G1J));
   }
   uint32_t half = (n + 1) / 2;
   ZK_ALLOC(ctx, buf0, G1J, half);

@@ -146,9 +146,9 @@ int zk_transcript::ensure(size_t add_fr, size_t add_g1) {
     size_t nc = cap_fr ? cap_fr : 1024;
     while (nc < n_fr + add_fr) nc *= 2;
     Fr* p = nullptr;
-    ZK_HIP(ctx, hipMallocAsync((void**)&p, nc * sizeof(Fr), ctx->stream));
-    if (n_fr) ZK_HIP(ctx, hipMemcpyAsync(p, fr_d, n_fr * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
-    if (fr_d) ZK_HIP(ctx, hipFreeAsync(fr_d, ctx->stream));
+    ZK_HIP(ctx, dev_alloc(ctx, (void**)&p, nc * sizeof(Fr)));
+    if (n_fr) ZK_TRY(dev_copy(ctx, p, fr_d, n_fr * sizeof(Fr)));
+    dev_free(ctx, fr_d);
     fr_d = p;
     cap_fr = nc;
   }
@@ -157,9 +157,9 @@ int zk_transcript::ensure(size_t add_fr, size_t add_g1) {
     size_t nc = cap_g1 ? cap_g1 : 1024;
     while (nc < n_g1 + add_g1) nc *= 2;
     G1J* p = nullptr;
-    ZK_HIP(ctx, hipMallocAsync((void**)&p, nc * sizeof(G1J), ctx->stream));
-    if (n_g1) ZK_HIP(ctx, hipMemcpyAsync(p, g1_d, n_g1 * sizeof(G1J), hipMemcpyDeviceToDevice, ctx->stream));
-    if (g1_d) ZK_HIP(ctx, hipFreeAsync(g1_d, ctx->stream));
+    ZK_HIP(ctx, dev_alloc(ctx, (void**)&p, nc * sizeof(G1J)));
+    if (n_g1) ZK_TRY(dev_copy(ctx, p, g1_d, n_g1 * sizeof(G1J)));
+    dev_free(ctx, g1_d);
     g1_d = p;
     cap_g1 = nc;
   }
@@ -187,11 +187,11 @@ int fc_create(zk_ctx* ctx, uint32_t in, uint32_t out, const Fr* weights_d, zk_ge
   fc->out = out;
   fc->m = (uint32_t)(wn / n_gens);
   fc->n_gens = n_gens;
-  if (hipMalloc((void**)&fc->weights, wn * sizeof(Fr)) != hipSuccess || gens_create(ctx, nullptr, fc->m, false, &fc->com) != ZK_OK) {
+  if (dev_alloc(ctx, (void**)&fc->weights, wn * sizeof(Fr)) != hipSuccess || gens_create(ctx, nullptr, fc->m, false, &fc->com) != ZK_OK) {
     zk_fc_destroy(fc);
     return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: zkFC");
   }
-  ZK_HIP(ctx, hipMemcpyAsync(fc->weights, weights_d, wn * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+  ZK_TRY(dev_copy(ctx, fc->weights, weights_d, wn * sizeof(Fr)));
   int rc = commit_dev(ctx, gens, fc->weights, (uint32_t)wn, fc->com->pts);
   if (rc != ZK_OK) {
     zk_fc_destroy(fc);
@@ -265,10 +265,10 @@ int relu_forward(zk_ctx* ctx, zk_relu* relu, const Fr* x, uint32_t n, Fr* z) {
   if (n == 0) return ZK_OK;
   if (relu->cap < n) {  // reset_ptrs, zkrelu.cu:54-63
     relu->free_all();
-    bool ok = hipMalloc((void**)&relu->sign, (size_t)n * sizeof(Fr)) == hipSuccess && hipMalloc((void**)&relu->mag_bin, (size_t)n * 32 * sizeof(Fr)) == hipSuccess &&
-              hipMalloc((void**)&relu->rem_bin, (size_t)n * 16 * sizeof(Fr)) == hipSuccess && hipMalloc((void**)&relu->mag_packed, (size_t)n * 4) == hipSuccess &&
-              hipMalloc((void**)&relu->rem_packed, (size_t)n * 2) == hipSuccess && hipMalloc((void**)&relu->sign_packed, (size_t)n) == hipSuccess &&
-              hipMalloc((void**)&relu->oor, 4) == hipSuccess;
+    bool ok = dev_alloc(ctx, (void**)&relu->sign, (size_t)n * sizeof(Fr)) == hipSuccess && dev_alloc(ctx, (void**)&relu->mag_bin, (size_t)n * 32 * sizeof(Fr)) == hipSuccess &&
+              dev_alloc(ctx, (void**)&relu->rem_bin, (size_t)n * 16 * sizeof(Fr)) == hipSuccess && dev_alloc(ctx, (void**)&relu->mag_packed, (size_t)n * 4) == hipSuccess &&
+              dev_alloc(ctx, (void**)&relu->rem_packed, (size_t)n * 2) == hipSuccess && dev_alloc(ctx, (void**)&relu->sign_packed, (size_t)n) == hipSuccess &&
+              dev_alloc(ctx, (void**)&relu->oor, 16) == hipSuccess;
     if (!ok) {
       relu->free_all();
       return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: zkReLU aux tensors");
@@ -276,12 +276,11 @@ int relu_forward(zk_ctx* ctx, zk_relu* relu, const Fr* x, uint32_t n, Fr* z) {
     relu->cap = n;
   }
   relu->n = n;
-  ZK_HIP(ctx, hipMemsetAsync(relu->oor, 0, 4, ctx->stream));
+  ZK_TRY(dev_zero(ctx, relu->oor, 4));
   ZK_LAUNCH(ctx, "relu_forward", 32ull * 51 * n, k_relu, dim3(stream_grid(n)), dim3(256), 0, x, z, relu->sign, relu->mag_bin, relu->rem_bin, relu->mag_packed,
             relu->rem_packed, relu->sign_packed, n, relu->oor);
   uint32_t oor = 0;
-  ZK_HIP(ctx, hipMemcpyAsync(&oor, relu->oor, 4, hipMemcpyDeviceToHost, ctx->stream));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_TRY(dev_to_host(ctx, &oor, relu->oor, 4));
   if (oor) return ctx->fail(ZK_ERR_RANGE, "zkReLU: " + std::to_string(oor) + " input(s) outside the +-2^47 window (undefined in the reference)");
   return ZK_OK;
 }
@@ -308,14 +307,25 @@ int relu_prove(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const Fr* z, uint3
   const Fr* c = chd.get();
   ZK_TRY(tr->ensure(3 * (k + 5) + 1 + 32 + 3 * (k + 4) + 1 + 16 + 3 * k + 2, 0));
   Fr* out = tr->fr_d + tr->n_fr;
-  ZK_TRY(sumcheck_bin_dev(ctx, relu->mag_bin, n * 32, c + offs[0], c + offs[1], k + 5, out));
-  out += 3 * (k + 5) + 1;
-  ZK_TRY(fr_partial_me_dev(ctx, relu->mag_bin, n * 32, c + offs[4], k, 32, out));
-  out += 32;
-  ZK_TRY(sumcheck_bin_dev(ctx, relu->rem_bin, n * 16, c + offs[2], c + offs[3], k + 4, out));
-  out += 3 * (k + 4) + 1;
-  ZK_TRY(fr_partial_me_dev(ctx, relu->rem_bin, n * 16, c + offs[4], k, 16, out));
-  out += 16;
+  if (ctx->relu_packed) {
+    ZK_TRY(binp_sumcheck_dev(ctx, relu->mag_packed, n, 32, c + offs[0], c + offs[1], k + 5, out));
+    out += 3 * (k + 5) + 1;
+    ZK_TRY(binp_partial_me_dev(ctx, relu->mag_packed, n, 32, c + offs[4], k, out));
+    out += 32;
+    ZK_TRY(binp_sumcheck_dev(ctx, relu->rem_packed, n, 16, c + offs[2], c + offs[3], k + 4, out));
+    out += 3 * (k + 4) + 1;
+    ZK_TRY(binp_partial_me_dev(ctx, relu->rem_packed, n, 16, c + offs[4], k, out));
+    out += 16;
+  } else {
+    ZK_TRY(sumcheck_bin_dev(ctx, relu->mag_bin, n * 32, c + offs[0], c + offs[1], k + 5, out));
+    out += 3 * (k + 5) + 1;
+    ZK_TRY(fr_partial_me_dev(ctx, relu->mag_bin, n * 32, c + offs[4], k, 32, out));
+    out += 32;
+    ZK_TRY(sumcheck_bin_dev(ctx, relu->rem_bin, n * 16, c + offs[2], c + offs[3], k + 4, out));
+    out += 3 * (k + 4) + 1;
+    ZK_TRY(fr_partial_me_dev(ctx, relu->rem_bin, n * 16, c + offs[4], k, 16, out));
+    out += 16;
+  }
   ZK_TRY(sumcheck_hp_dev(ctx, x, relu->sign, n, c + offs[5], c + offs[6], k, out));
   out += 3 * k + 2;
   tr->n_fr = (size_t)(out - tr->fr_d);

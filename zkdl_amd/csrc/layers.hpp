@@ -47,8 +47,8 @@ struct zk_relu {  // zkReLU, zkrelu.cuh:10-20: aux tensors of the last forward p
   uint8_t* sign_packed = nullptr;
   uint32_t* oor = nullptr;
   void free_all() {
-    (void)hipFree(sign); (void)hipFree(mag_bin); (void)hipFree(rem_bin);
-    (void)hipFree(mag_packed); (void)hipFree(rem_packed); (void)hipFree(sign_packed); (void)hipFree(oor);
+    zk::dev_free(ctx, sign); zk::dev_free(ctx, mag_bin); zk::dev_free(ctx, rem_bin);
+    zk::dev_free(ctx, mag_packed); zk::dev_free(ctx, rem_packed); zk::dev_free(ctx, sign_packed); zk::dev_free(ctx, oor);
     sign = mag_bin = rem_bin = nullptr;
     mag_packed = nullptr; rem_packed = nullptr; sign_packed = nullptr; oor = nullptr;
     cap = n = 0;
@@ -68,6 +68,8 @@ struct zk_transcript {  // proof values in the order of SURVEY.md App. A.6, resi
 
 namespace zk {
 int transcript_digest_dev(zk_ctx* ctx, const Fr* fr, size_t n_fr, const G1J* g1, size_t n_g1, Fr* out_fr_d, uint64_t* out8_d);
+int binp_sumcheck_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb, const Fr* u_d, const Fr* v_d, uint32_t k, Fr* proof_d);
+int binp_partial_me_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb, const Fr* u_d, uint32_t k, Fr* out_d);
 int float_to_fr_dev(zk_ctx* ctx, const float* fs, Fr* out, uint32_t rows, uint32_t rows_p, uint32_t cols, uint32_t cols_p);
 int gens_create(zk_ctx* ctx, const G1J* gens_d, uint32_t n, bool copy, zk_gens** out);
 void gens_destroy(zk_gens* g);

@@ -63,7 +63,7 @@ int gens_table(zk_ctx* ctx, zk_gens* g, uint32_t c, uint32_t W, const G1Table** 
   T.c = c;
   T.W = W;
   size_t total = (size_t)W * g->n;
-  if (hipMalloc((void**)&T.pts, total * sizeof(G1A)) != hipSuccess || hipMalloc((void**)&T.inf, total) != hipSuccess)
+  if (dev_alloc(ctx, (void**)&T.pts, total * sizeof(G1A)) != hipSuccess || dev_alloc(ctx, (void**)&T.inf, total) != hipSuccess)
     return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: MSM window table");
   {
     ZK_ALLOC(ctx, jac, G1J, total);
@@ -73,9 +73,9 @@ int gens_table(zk_ctx* ctx, zk_gens* g, uint32_t c, uint32_t W, const G1Table** 
   if (it != g->tables.end()) {
     // a wider table replaces a narrower one IN PLACE: queued jobs hold a pointer to this map node and
     // pick up the new (superset) arrays when they run; the old arrays go once the stream has drained
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(it->second.pts);
-    (void)hipFree(it->second.inf);
+    // (queued jobs have not been launched yet; launched ones are ordered before these frees)
+    dev_free(ctx, it->second.pts);
+    dev_free(ctx, it->second.inf);
     it->second = T;
     *out = &it->second;
     return ZK_OK;
@@ -403,11 +403,8 @@ int msm_run_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs, uint32_t c) 
     // job table through the pinned staging ring (large batches: chunked synchronous copy)
     size_t bytes = (size_t)nj * sizeof(MsmJob);
     void* st = bytes <= (1u << 20) ? ctx->stage_put(jobs.data(), bytes) : nullptr;
-    if (st) ZK_HIP(ctx, hipMemcpyAsync(djobs.get(), st, bytes, hipMemcpyHostToDevice, ctx->stream));
-    else {
-      ZK_HIP(ctx, hipMemcpyAsync(djobs.get(), jobs.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
-      ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
+    if (st) ZK_TRY(dev_copy(ctx, djobs.get(), st, bytes));
+    else ZK_TRY(host_to_dev(ctx, djobs.get(), jobs.data(), bytes));
   }
   ZK_ALLOC(ctx, idx, uint32_t, items);
   ZK_ALLOC(ctx, off, uint32_t, (size_t)nj * (B + 2));
@@ -435,12 +432,11 @@ int msm_enqueue(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_
   DBuf<Fr> mags;
   if (!mags.alloc(ctx, total)) return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: MSM scalars");
   ZK_ALLOC(ctx, maxbits, uint32_t, 1);
-  ZK_HIP(ctx, hipMemsetAsync(maxbits.get(), 0, 4, ctx->stream));
+  ZK_TRY(dev_zero(ctx, maxbits.get(), 4));
   ZK_LAUNCH(ctx, "msm_scalar_prep", 64ull * total, k_scalar_prep, dim3(stream_grid(total)), dim3(256), 0, scalars, mags.get(), total, do_unmont ? 1 : 0, maxbits.get());
   uint32_t bits = 254;
   if (probe_bits) {  // setup-time paths only (commit): one host round trip buys 10x fewer windows
-    ZK_HIP(ctx, hipMemcpyAsync(&bits, maxbits.get(), 4, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_TRY(dev_to_host(ctx, &bits, maxbits.get(), 4));
   }
   uint32_t c = msm_pick_window(ctx, bits);
   uint32_t W = msm_num_windows(bits, c);
@@ -516,13 +512,13 @@ int me_open_flat_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32
   if (k > 19 || n != (1u << k)) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions (flattened me_open needs n == 2^k)");
   // folded scalar tensors S_0 .. S_k (Fr only, tiny)
   ZK_ALLOC(ctx, S, Fr, 2ull * n + 2);
-  ZK_HIP(ctx, hipMemcpyAsync(S.get(), t, (size_t)n * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+  ZK_TRY(dev_copy(ctx, S.get(), t, (size_t)n * sizeof(Fr)));
   for (uint32_t r = 0; r < k; r++) {
     Fr* cur = S.get() + (2ull * n - ((2ull * n) >> r));
     Fr* nxt = S.get() + (2ull * n - ((2ull * n) >> (r + 1)));
     ZK_TRY(fr_fold_dev(ctx, cur, nxt, u_d + r, n >> r, n >> (r + 1)));
   }
-  ZK_HIP(ctx, hipMemcpyAsync(ret_d, S.get() + (2ull * n - 2), sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));  // t(0) = S_k[0]
+  ZK_TRY(dev_copy(ctx, ret_d, S.get() + (2ull * n - 2), sizeof(Fr)));  // t(0) = S_k[0]
   uint32_t ncoef = (2u << k) - 1u;
   ZK_ALLOC(ctx, C, Fr, ncoef);
   ZK_LAUNCH(ctx, "me_open_scalars", 32ull * ncoef, k_mo_coef, dim3((ncoef + 255) / 256), dim3(256), 0, u_d, k, C.get());
