@@ -409,3 +409,21 @@ def test_relu_prove_packed_equals_unpacked_and_oracle(zk, oracle, rng, n):
     if n <= 300:
         wA, wsign, wmag, wrem = oracle.relu_forward(X)
         assert eq(out[1], oracle.relu_prove(X, wA, wsign, wmag, wrem, *ch))
+
+
+def test_lanes_and_deferred_msm_do_not_change_the_transcript(zk, oracle):
+    """Worker lanes (independent layers on separate HIP streams) and the deferred MSM batch are pure
+    scheduling: the transcript must be identical with lanes on and off, run after run."""
+    from mlp_util import prove_mlp_gpu, synth_mlp
+    from zkdl_amd.capi import MSM_PIPPENGER
+    zk.set_msm_mode(MSM_PIPPENGER)
+    model = synth_mlp(oracle, [16, 32, 24, 8], 4, seed=21)
+    gens = [zk.gens(zk.upload(g)) for g in model["gens"]]
+    runs = []
+    for lanes in (1, 0, 1):
+        zk.set_flag("lanes", lanes)
+        fr, aff, inf, info = prove_mlp_gpu(zk, model, gens_dev=gens)
+        runs.append((fr, aff, inf, info["tr"].digest()))
+    zk.set_flag("lanes", 1)
+    for r in runs[1:]:
+        assert eq(r[0], runs[0][0]) and eq(r[1], runs[0][1]) and eq(r[2], runs[0][2]) and eq(r[3], runs[0][3])

@@ -13,7 +13,11 @@ using namespace zk;
 static_assert(sizeof(zk_fr) == sizeof(Fr) && sizeof(zk_fp) == sizeof(Fp), "POD layout");
 static_assert(sizeof(zk_g1a) == sizeof(G1A) && sizeof(zk_g1j) == sizeof(G1J), "POD layout");
 
-#define CHECK_CTX(ctx) \
+// every entry point except the lane-parallel provers first joins the worker lanes
+#define CHECK_CTX(ctx)            \
+  if (!(ctx)) return ZK_ERR_ARG;  \
+  (ctx)->join_lanes()
+#define CHECK_CTX_NOJOIN(ctx) \
   if (!(ctx)) return ZK_ERR_ARG
 #define CHECK_PTR(ctx, p)                                                                  \
   if (!(p) || (((uintptr_t)(p)) & 15u)) return (ctx)->fail(ZK_ERR_ARG, "null or misaligned pointer: " #p)
@@ -36,8 +40,8 @@ void* zk_ctx::stage_put(const void* src, size_t bytes) {
   size_t need = (bytes + 63) & ~(size_t)63;
   if (need > stage_cap) return nullptr;
   if (stage_off + need > stage_cap) {
-    // ring wrapped: everything staged so far must have been consumed
-    if (hipStreamSynchronize(stream) != hipSuccess) return nullptr;
+    // ring wrapped: everything staged so far (on any lane) must have been consumed
+    if (hipDeviceSynchronize() != hipSuccess) return nullptr;
     stage_off = 0;
   }
   void* dst = stage + stage_off;
@@ -48,7 +52,8 @@ void* zk_ctx::stage_put(const void* src, size_t bytes) {
 
 void zk_ctx::prof_flush() {
   if (pending.empty()) return;
-  (void)hipStreamSynchronize(stream);
+  join_lanes();
+  (void)hipStreamSynchronize(main_stream);
   for (auto& p : pending) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
@@ -77,9 +82,22 @@ int zk_ctx_create(int device, zk_ctx** out) {
   zk_ctx* ctx = new zk_ctx();
   ctx->device = device;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&ctx->t0) != hipSuccess ||
-      hipEventCreate(&ctx->t1) != hipSuccess) {
+      hipEventCreate(&ctx->t1) != hipSuccess || hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming) != hipSuccess) {
     delete ctx;
     return ZK_ERR_DEVICE;
+  }
+  ctx->main_stream = ctx->stream;
+  {
+    int nl = 8;
+    if (const char* e = getenv("ZKDL_LANES")) nl = atoi(e);
+    if (nl < 0) nl = 0;
+    if (nl > 16) nl = 16;
+    ctx->lanes.resize((size_t)nl);
+    for (auto& l : ctx->lanes)
+      if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&l.done, hipEventDisableTiming) != hipSuccess) {
+        ctx->lanes.clear();  // no lanes: everything stays on the main stream
+        break;
+      }
   }
   ctx->stage_cap = 4u << 20;
   if (hipHostMalloc((void**)&ctx->stage, ctx->stage_cap, hipHostMallocDefault) != hipSuccess) {
@@ -92,24 +110,30 @@ int zk_ctx_create(int device, zk_ctx** out) {
 int zk_ctx_destroy(zk_ctx* ctx) {
   if (!ctx) return ZK_ERR_ARG;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  ctx->join_lanes();
+  (void)hipDeviceSynchronize();
   ctx->prof_flush();
+  for (auto& l : ctx->lanes) {
+    if (l.stream) (void)hipStreamDestroy(l.stream);
+    if (l.done) (void)hipEventDestroy(l.done);
+  }
+  (void)hipEventDestroy(ctx->fork_ev);
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   (void)hipEventDestroy(ctx->t0);
   (void)hipEventDestroy(ctx->t1);
   (void)hipHostFree(ctx->stage);
   ctx->pool_destroy();
-  (void)hipStreamDestroy(ctx->stream);
+  (void)hipStreamDestroy(ctx->main_stream);
   delete ctx;
   return ZK_OK;
 }
 int zk_ctx_sync(zk_ctx* ctx) {
   CHECK_CTX(ctx);
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->main_stream));
   return ZK_OK;
 }
 const char* zk_last_error(const zk_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
-void* zk_ctx_stream(zk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+void* zk_ctx_stream(zk_ctx* ctx) { return ctx ? (void*)ctx->main_stream : nullptr; }
 
 int zk_malloc(zk_ctx* ctx, size_t bytes, void** out_d) {
   CHECK_CTX(ctx);
@@ -441,6 +465,7 @@ int zk_set_flag(zk_ctx* ctx, const char* name, int value) {
   CHECK_CTX(ctx);
   CHECK_HOST(ctx, name);
   if (!strcmp(name, "relu_packed")) ctx->relu_packed = value != 0;
+  else if (!strcmp(name, "lanes")) ctx->lanes_enabled = value != 0;
   else return ctx->fail(ZK_ERR_ARG, std::string("unknown flag: ") + name);
   return ZK_OK;
 }
@@ -457,6 +482,7 @@ int zk_gens_create(zk_ctx* ctx, const zk_g1j* gens, uint32_t n, zk_gens** out) {
 }
 int zk_gens_destroy(zk_gens* g) {
   if (!g) return ZK_ERR_ARG;
+  if (g->ctx) g->ctx->join_lanes();
   gens_destroy(g);
   return ZK_OK;
 }
@@ -538,6 +564,7 @@ int zk_fc_from_float(zk_ctx* ctx, uint32_t in, uint32_t out, const float* w, zk_
 }
 int zk_fc_destroy(zk_fc* fc) {
   if (!fc) return ZK_ERR_ARG;
+  if (fc->ctx) fc->ctx->join_lanes();
   if (fc->ctx) dev_free(fc->ctx, fc->weights);
   gens_destroy(fc->com);
   delete fc;
@@ -563,7 +590,7 @@ int zk_fc_forward(zk_ctx* ctx, const zk_fc* fc, const zk_fr* x, uint32_t xn, zk_
 }
 int zk_fc_prove(zk_ctx* ctx, zk_fc* fc, const zk_fr* x, uint32_t xn, const zk_fr* z, uint32_t zn, zk_gens* gens, const zk_fr* u_bs_h,
                 const zk_fr* u_in_h, const zk_fr* u_out_h, zk_transcript* tr) {
-  CHECK_CTX(ctx);
+  CHECK_CTX_NOJOIN(ctx);
   if (!fc || !tr || !gens) return ctx->fail(ZK_ERR_ARG, "null zk_fc / zk_gens / zk_transcript");
   CHECK_PTR(ctx, x); CHECK_PTR(ctx, z);
   return fc_prove(ctx, fc, F(x), xn, F(z), zn, gens, u_bs_h, u_in_h, u_out_h, tr);
@@ -577,6 +604,7 @@ int zk_relu_create(zk_ctx* ctx, zk_relu** out) {
 }
 int zk_relu_destroy(zk_relu* relu) {
   if (!relu) return ZK_ERR_ARG;
+  if (relu->ctx) relu->ctx->join_lanes();
   relu->free_all();
   delete relu;
   return ZK_OK;
@@ -592,7 +620,7 @@ const zk_fr* zk_relu_mag_bin(const zk_relu* r) { return r ? reinterpret_cast<con
 const zk_fr* zk_relu_rem_bin(const zk_relu* r) { return r ? reinterpret_cast<const zk_fr*>(r->rem_bin) : nullptr; }
 int zk_relu_prove(zk_ctx* ctx, const zk_relu* relu, const zk_fr* x, const zk_fr* z, uint32_t n, const zk_fr* u_z, const zk_fr* v_z, const zk_fr* u_r,
                   const zk_fr* v_r, const zk_fr* u_rec, const zk_fr* u_hp, const zk_fr* v_hp, zk_transcript* tr) {
-  CHECK_CTX(ctx);
+  CHECK_CTX_NOJOIN(ctx);
   if (!relu || !tr) return ctx->fail(ZK_ERR_ARG, "null zk_relu / zk_transcript");
   CHECK_PTR(ctx, x); CHECK_PTR(ctx, z);
   return relu_prove(ctx, relu, F(x), F(z), n, u_z, v_z, u_r, v_r, u_rec, u_hp, v_hp, tr);
@@ -608,6 +636,7 @@ int zk_transcript_create(zk_ctx* ctx, zk_transcript** out) {
 }
 int zk_transcript_destroy(zk_transcript* tr) {
   if (!tr) return ZK_ERR_ARG;
+  tr->ctx->join_lanes();
   (void)tr->flush();
   dev_free(tr->ctx, tr->fr_d);
   dev_free(tr->ctx, tr->g1_d);
@@ -616,16 +645,19 @@ int zk_transcript_destroy(zk_transcript* tr) {
 }
 int zk_transcript_reset(zk_transcript* tr) {
   if (!tr) return ZK_ERR_ARG;
+  tr->ctx->join_lanes();
   int rc = tr->flush();  // pending MSMs own scratch that must be released in stream order
   tr->n_fr = tr->n_g1 = tr->n_g1_final = 0;
   return rc;
 }
 int zk_transcript_flush(zk_transcript* tr) {
   if (!tr) return ZK_ERR_ARG;
+  tr->ctx->join_lanes();
   return tr->flush();
 }
 int zk_transcript_counts(zk_transcript* tr, size_t* n_fr, size_t* n_g1) {
   if (!tr) return ZK_ERR_ARG;
+  tr->ctx->join_lanes();
   ZK_TRY(tr->flush());
   ZK_HIP(tr->ctx, hipStreamSynchronize(tr->ctx->stream));
   if (n_fr) *n_fr = tr->n_fr;
@@ -635,6 +667,7 @@ int zk_transcript_counts(zk_transcript* tr, size_t* n_fr, size_t* n_g1) {
 int zk_transcript_read(zk_transcript* tr, zk_fr* fr_h, size_t fr_cap, zk_g1j* g1_h, size_t g1_cap) {
   if (!tr) return ZK_ERR_ARG;
   zk_ctx* ctx = tr->ctx;
+  ctx->join_lanes();
   if (fr_cap < tr->n_fr || g1_cap < tr->n_g1) return ctx->fail(ZK_ERR_ARG, "transcript buffers too small");
   ZK_TRY(tr->flush());
   if (tr->n_fr) ZK_TRY(zk_memcpy_d2h(ctx, fr_h, tr->fr_d, tr->n_fr * sizeof(Fr)));
@@ -644,6 +677,7 @@ int zk_transcript_read(zk_transcript* tr, zk_fr* fr_h, size_t fr_cap, zk_g1j* g1
 int zk_transcript_read_affine(zk_transcript* tr, zk_g1a* g1_h, uint8_t* inf_h, size_t cap) {
   if (!tr) return ZK_ERR_ARG;
   zk_ctx* ctx = tr->ctx;
+  ctx->join_lanes();
   if (cap < tr->n_g1) return ctx->fail(ZK_ERR_ARG, "transcript buffers too small");
   ZK_TRY(tr->flush());
   if (!tr->n_g1) return zk_ctx_sync(ctx);
@@ -656,6 +690,7 @@ int zk_transcript_read_affine(zk_transcript* tr, zk_g1a* g1_h, uint8_t* inf_h, s
 int zk_transcript_digest(zk_transcript* tr, zk_fr* out_h) {
   if (!tr) return ZK_ERR_ARG;
   zk_ctx* ctx = tr->ctx;
+  ctx->join_lanes();
   CHECK_HOST(ctx, out_h);
   ZK_TRY(tr->flush());
   ZK_ALLOC(ctx, d, Fr, 1);
@@ -665,6 +700,7 @@ int zk_transcript_digest(zk_transcript* tr, zk_fr* out_h) {
 int zk_transcript_digest_dev(zk_transcript* tr, uint64_t* out8_d) {
   if (!tr) return ZK_ERR_ARG;
   zk_ctx* ctx = tr->ctx;
+  ctx->join_lanes();
   if (!out8_d || (((uintptr_t)out8_d) & 7u)) return ctx->fail(ZK_ERR_ARG, "null or misaligned pointer: out8_d");
   ZK_TRY(tr->flush());
   return transcript_digest_dev(ctx, tr->fr_d, tr->n_fr, tr->g1_d, tr->n_g1, nullptr, out8_d);

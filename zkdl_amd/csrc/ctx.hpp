@@ -54,33 +54,42 @@ struct zk_ctx {
   void* stage_put(const void* src, size_t bytes);  // returns pinned address holding a copy
 
   // ---- device memory: a size-class caching allocator over plain hipMalloc blocks.
-  // All work of a context is enqueued on ONE stream, so a block may be handed out again as soon as it
-  // is released: every later use is ordered behind every earlier use.  Blocks are never returned to
-  // the driver before the context dies (288 GB of HBM), so steady-state proving makes no allocator
-  // calls into the runtime at all.  (hipMallocAsync/hipFreeAsync were dropped: on ROCm 7.2 the
-  // stream-ordered pool was observed to hand a still-live block out a second time.)
-  std::unordered_map<void*, size_t> pool_size;               // every block ever allocated -> class size
-  std::unordered_map<void*, bool> pool_idle;                 // double-release guard
-  uint64_t pool_double_release = 0;
-  std::map<size_t, std::vector<void*>> pool_free_lists;      // class size -> idle blocks
+  // A block may be handed out again as soon as it is released, PROVIDED every later use is ordered
+  // behind every earlier use.  That holds per stream, so every stream ("lane", below) has its own pool:
+  // a block is only ever re-issued by the pool that first issued it, i.e. to work on the same stream
+  // (or on the main stream after that lane has been joined).  Blocks are never returned to the driver
+  // before the context dies (288 GB of HBM), so steady-state proving makes no allocator calls into the
+  // runtime at all.  (hipMallocAsync/hipFreeAsync were dropped: on ROCm 7.2 the stream-ordered pool was
+  // observed to hand a still-live block out a second time.)
+  struct Pool {
+    std::map<size_t, std::vector<void*>> free_lists;  // class size -> idle blocks
+  };
+  struct Block {
+    size_t cls;
+    Pool* owner;
+    bool idle;
+  };
+  std::unordered_map<void*, Block> blocks;  // every block ever allocated
+  Pool main_pool;
+  Pool* cur_pool = &main_pool;
   size_t pool_bytes = 0;
+  uint64_t pool_double_release = 0;
   static size_t pool_class(size_t bytes) {
     if (bytes < 256) return 256;
-    // 4 classes per octave: waste <= 19 %
     size_t p = 256;
-    while (p < bytes) p <<= 1;          // smallest power of two >= bytes
-    size_t q = p >> 3;                  // eighth of it
+    while (p < bytes) p <<= 1;  // smallest power of two >= bytes
+    size_t q = p >> 3;          // 4 classes per octave: waste <= 19 %
     for (size_t c = (p >> 1) + q; c < p; c += q)
       if (c >= bytes) return c;
     return p;
   }
   void* pool_alloc(size_t bytes) {
     size_t cls = pool_class(bytes);
-    auto& fl = pool_free_lists[cls];
+    auto& fl = cur_pool->free_lists[cls];
     if (!fl.empty()) {
       void* p = fl.back();
       fl.pop_back();
-      pool_idle[p] = false;
+      blocks[p].idle = false;
       return p;
     }
     void* p = nullptr;
@@ -88,28 +97,51 @@ struct zk_ctx {
       (void)hipGetLastError();
       return nullptr;
     }
-    pool_size[p] = cls;
-    pool_idle[p] = false;
+    blocks[p] = Block{cls, cur_pool, false};
     pool_bytes += cls;
     return p;
   }
   void pool_release(void* p) {
     if (!p) return;
-    auto it = pool_size.find(p);
-    if (it == pool_size.end()) return;  // not ours (never happens for library-made pointers)
-    bool& idle = pool_idle[p];
-    if (idle) {  // releasing twice would hand one block to two owners: refuse and remember
+    auto it = blocks.find(p);
+    if (it == blocks.end()) return;  // not ours (never happens for library-made pointers)
+    if (it->second.idle) {  // releasing twice would hand one block to two owners: refuse and remember
       ++pool_double_release;
       last_error = "internal error: device block released twice";
       return;
     }
-    idle = true;
-    pool_free_lists[it->second].push_back(p);
+    it->second.idle = true;
+    it->second.owner->free_lists[it->second.cls].push_back(p);
   }
   void pool_destroy() {
-    for (auto& kv : pool_size) (void)hipFree(kv.first);
-    pool_size.clear();
-    pool_free_lists.clear();
+    for (auto& kv : blocks) (void)hipFree(kv.first);
+    blocks.clear();
+    main_pool.free_lists.clear();
+    for (auto& l : lanes) l.pool.free_lists.clear();
+  }
+
+  // ---- lanes: worker streams for independent per-layer proofs (zk_fc_prove / zk_relu_prove).
+  // All challenges are known up front, so the layers' sumchecks are independent; running them on a few
+  // streams overlaps their many small, latency-bound launches.  A lane scope forks from the main stream
+  // (event wait), swaps ctx->stream / cur_pool, and records a `done` event when it ends; every other
+  // entry point first makes the main stream wait on all dirty lanes (join_lanes).
+  struct Lane {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    Pool pool;
+    bool dirty = false;
+  };
+  std::vector<Lane> lanes;
+  hipStream_t main_stream = nullptr;
+  hipEvent_t fork_ev = nullptr;
+  uint32_t next_lane = 0;
+  bool lanes_enabled = true;
+  void join_lanes() {
+    for (auto& l : lanes)
+      if (l.dirty) {
+        (void)hipStreamWaitEvent(main_stream, l.done, 0);
+        l.dirty = false;
+      }
   }
 
   int fail(int code, const std::string& msg) {
@@ -162,6 +194,27 @@ struct ProfScope {
       (void)hipEventRecord(b, ctx->stream);
       ctx->pending.push_back({name, bytes, a, b});
     }
+  }
+};
+
+// RAII: run the enclosed work on the next worker lane (no-op when lanes are disabled or unavailable).
+struct LaneScope {
+  zk_ctx* ctx;
+  zk_ctx::Lane* lane = nullptr;
+  explicit LaneScope(zk_ctx* c) : ctx(c) {
+    if (!c->lanes_enabled || c->lanes.empty() || c->stream != c->main_stream) return;
+    lane = &c->lanes[c->next_lane++ % c->lanes.size()];
+    (void)hipEventRecord(c->fork_ev, c->main_stream);
+    (void)hipStreamWaitEvent(lane->stream, c->fork_ev, 0);
+    c->stream = lane->stream;
+    c->cur_pool = &lane->pool;
+  }
+  ~LaneScope() {
+    if (!lane) return;
+    (void)hipEventRecord(lane->done, lane->stream);
+    lane->dirty = true;
+    ctx->stream = ctx->main_stream;
+    ctx->cur_pool = &ctx->main_pool;
   }
 };
 

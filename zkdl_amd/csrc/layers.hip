@@ -142,8 +142,11 @@ using namespace zk;
 
 // ------------------------------------------------------------------ transcript
 int zk_transcript::ensure(size_t add_fr, size_t add_g1) {
+  if (n_fr + add_fr > cap_fr || n_g1 + add_g1 > cap_g1) ctx->join_lanes();  // lanes may still be writing the old buffers
   if (n_fr + add_fr > cap_fr) {
-    size_t nc = cap_fr ? cap_fr : 1024;
+    size_t want = n_fr + add_fr;
+    (void)want;
+    size_t nc = cap_fr ? cap_fr : 8192;
     while (nc < n_fr + add_fr) nc *= 2;
     Fr* p = nullptr;
     ZK_HIP(ctx, dev_alloc(ctx, (void**)&p, nc * sizeof(Fr)));
@@ -167,6 +170,7 @@ int zk_transcript::ensure(size_t add_fr, size_t add_g1) {
 }
 
 int zk_transcript::flush() {
+  ctx->join_lanes();
   ZK_TRY(msm_flush(ctx, &queue));
   if (n_g1 > n_g1_final && ctx->msm_mode == ZK_MSM_PIPPENGER) ZK_TRY(g1_canonicalise_dev(ctx, g1_d + n_g1_final, (uint32_t)(n_g1 - n_g1_final)));
   n_g1_final = n_g1;
@@ -219,6 +223,19 @@ int fc_prove(zk_ctx* ctx, zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint
   const uint32_t batch = xn / fc->in;
   const uint32_t k_bs = ceil_log2(batch), k_in = ceil_log2(fc->in), k_out = ceil_log2(fc->out);
   const uint32_t wn = fc->in * fc->out;
+  const uint32_t k_lo = ceil_log2(n_gens), k_hi = ceil_log2(fc->m);
+  if (k_out + k_in < k_hi || k_out + k_in - k_hi != k_lo) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
+  uint32_t asz = fr_partial_me_size(xn, k_bs, fc->in), bsz = fr_partial_me_size(wn, k_out, 1);
+  if (asz != bsz) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
+  // reserve this call's transcript slots on the main timeline, then run the layer on a worker lane
+  const size_t add_fr = 3 * k_in + 2 + 1 + 1, add_g1 = 1 + 3 * k_lo + 1;
+  ZK_TRY(tr->ensure(add_fr, add_g1));
+  Fr* const fr_slot = tr->fr_d + tr->n_fr;
+  G1J* const g1_slot = tr->g1_d + tr->n_g1;
+  tr->n_fr += add_fr;
+  tr->n_g1 += add_g1;
+  LaneScope lane(ctx);  // declared before every temporary: they are released while the lane is current
+
   // all challenges of this layer in one device array: [u_out | u_in | u_bs]  (so u_out||u_in is contiguous)
   std::vector<zk_fr> ch(k_out + k_in + k_bs + 1);
   for (uint32_t i = 0; i < k_out; i++) ch[i] = u_out_h[i];
@@ -237,26 +254,16 @@ int fc_prove(zk_ctx* ctx, zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint
     for (uint32_t i = 0; i < k_bs; i++) z_[k_out + i] = u_bs_h[i];
     ZK_TRY(upload_fr(ctx, uz, z_.data(), k_out + k_bs));
   }
-  const uint32_t k_lo = ceil_log2(n_gens);
-  ZK_TRY(tr->ensure(3 * k_in + 4, 3 * k_lo + 2));
-
   // a = X.partial_me(u_bs, in) ; b = W.partial_me(u_out, 1)
-  uint32_t asz = fr_partial_me_size(xn, k_bs, fc->in), bsz = fr_partial_me_size(wn, k_out, 1);
-  if (asz != bsz) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   ZK_ALLOC(ctx, a, Fr, asz);
   ZK_ALLOC(ctx, b, Fr, bsz);
   ZK_TRY(fr_partial_me_dev(ctx, x, xn, u_bs, k_bs, fc->in, a.get()));
   ZK_TRY(fr_partial_me_dev(ctx, fc->weights, wn, u_out, k_out, 1, b.get()));
-  ZK_TRY(sumcheck_ip_dev(ctx, a.get(), b.get(), asz, u_in, k_in, tr->fr_d + tr->n_fr));
-  tr->n_fr += 3 * k_in + 2;
+  ZK_TRY(sumcheck_ip_dev(ctx, a.get(), b.get(), asz, u_in, k_in, fr_slot));
   // Z(u_Z)
-  ZK_TRY(fr_me_dev(ctx, z, zn, uz.get(), k_out + k_bs, tr->fr_d + tr->n_fr));
-  tr->n_fr += 1;
+  ZK_TRY(fr_me_dev(ctx, z, zn, uz.get(), k_out + k_bs, fr_slot + 3 * k_in + 2));
   // generators.open(weights, com, u_out || u_in)
-  if (k_out + k_in < ceil_log2(fc->m)) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
-  ZK_TRY(open_dev(ctx, gens, fc->weights, wn, fc->com, u_out, k_out + k_in, tr->g1_d + tr->n_g1, tr->g1_d + tr->n_g1 + 1, tr->fr_d + tr->n_fr, &tr->queue));
-  tr->n_fr += 1;
-  tr->n_g1 += 1 + 3 * (k_out + k_in - ceil_log2(fc->m)) + 1;
+  ZK_TRY(open_dev(ctx, gens, fc->weights, wn, fc->com, u_out, k_out + k_in, g1_slot, g1_slot + 1, fr_slot + 3 * k_in + 3, &tr->queue));
   return ZK_OK;
 }
 
@@ -292,6 +299,12 @@ int relu_prove(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const Fr* z, uint3
   if (relu->n != n || n == 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");  // zkrelu.cu:81
   if ((uint64_t)n * 32 > 0xffffffffull) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   const uint32_t k = ceil_log2(n);
+  const size_t add_fr = 3 * (k + 5) + 1 + 32 + 3 * (k + 4) + 1 + 16 + 3 * k + 2;
+  ZK_TRY(tr->ensure(add_fr, 0));
+  Fr* out = tr->fr_d + tr->n_fr;
+  tr->n_fr += add_fr;
+  LaneScope lane(ctx);  // declared before every temporary
+
   const uint32_t lens[7] = {k + 5, k + 5, k + 4, k + 4, k, k, k};
   const zk_fr* hs[7] = {u_z_h, v_z_h, u_r_h, v_r_h, u_rec_h, u_hp_h, v_hp_h};
   std::vector<zk_fr> ch;
@@ -305,8 +318,6 @@ int relu_prove(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const Fr* z, uint3
   DBuf<Fr> chd;
   ZK_TRY(upload_fr(ctx, chd, ch.data(), tot));
   const Fr* c = chd.get();
-  ZK_TRY(tr->ensure(3 * (k + 5) + 1 + 32 + 3 * (k + 4) + 1 + 16 + 3 * k + 2, 0));
-  Fr* out = tr->fr_d + tr->n_fr;
   if (ctx->relu_packed) {
     ZK_TRY(binp_sumcheck_dev(ctx, relu->mag_packed, n, 32, c + offs[0], c + offs[1], k + 5, out));
     out += 3 * (k + 5) + 1;
@@ -327,8 +338,6 @@ int relu_prove(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const Fr* z, uint3
     out += 16;
   }
   ZK_TRY(sumcheck_hp_dev(ctx, x, relu->sign, n, c + offs[5], c + offs[6], k, out));
-  out += 3 * k + 2;
-  tr->n_fr = (size_t)(out - tr->fr_d);
   return ZK_OK;
 }
 

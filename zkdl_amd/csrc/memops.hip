@@ -42,12 +42,14 @@ int dev_zero(zk_ctx* ctx, void* dst, size_t bytes) {
 // blocking host <-> device transfers: drain the stream first, then a synchronous copy
 int host_to_dev(zk_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return ZK_OK;
+  ctx->join_lanes();
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ZK_HIP(ctx, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
   return ZK_OK;
 }
 int dev_to_host(zk_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return ZK_OK;
+  ctx->join_lanes();
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ZK_HIP(ctx, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
   return ZK_OK;

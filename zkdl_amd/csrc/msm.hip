@@ -440,7 +440,10 @@ int msm_enqueue(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_
   }
   uint32_t c = msm_pick_window(ctx, bits);
   uint32_t W = msm_num_windows(bits, c);
-  if (queue->c != 0 && queue->c != c) ZK_TRY(msm_flush(ctx, queue));  // one window width per batch
+  if (queue->c != 0 && queue->c != c) {  // one window width per batch
+    if (ctx->stream != ctx->main_stream) return ctx->fail(ZK_ERR_ARG, "MSM: window width changed inside a deferred batch");
+    ZK_TRY(msm_flush(ctx, queue));
+  }
   queue->c = c;
   const G1Table* T = nullptr;
   ZK_TRY(gens_table(ctx, g, c, W, &T));
