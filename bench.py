@@ -270,15 +270,40 @@ def main():
     total_ms = sum(v["ms"] for v in prof.values()) or 1.0
     kernels = {k: {"ms_per_step": v["ms"] / nprof, "share": v["ms"] / total_ms, "launches_per_step": v["launches"] // nprof,
                    "alg_GBps": (v["bytes"] / v["ms"] / 1e6) if v["ms"] > 0 else 0.0} for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
-    # roofline for the dominant HBM-streaming kernel family of the proof (the sumcheck round kernels)
-    hbm_names = [k for k in kernels if k.startswith("sumcheck_") and k.endswith("_round")] or list(kernels)[:1]
-    dom = max(hbm_names, key=lambda k: kernels[k]["ms_per_step"])
+    # roofline for the dominant HBM-streaming kernel family of the timed region.  achieved = algorithmic
+    # bytes per launch / average launch duration (HIP events on the launching stream).
+    hbm_families = {"sumcheck_bin_round": "void zk::k_sc_round<2>", "sumcheck_hp_round": "void zk::k_sc_round<1>", "sumcheck_ip_round": "void zk::k_sc_round<0>",
+                    "fr_contract": "zk::k_colsum", "binp_rounds": "void zk::k_binp_rounds<32, unsigned int>", "fr_fold": "zk::k_fr_fold"}
+    cands = [k for k in kernels if k in hbm_families] or list(kernels)[:1]
+    dom = max(cands, key=lambda k: kernels[k]["ms_per_step"])
     pv = prof[dom]
     achieved = pv["bytes"] / pv["ms"] / 1e6 if pv["ms"] > 0 else 0.0
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/pmc_summary.py);
+        # gfx950 correction: FETCH_SIZE counts half the bytes of a 16-B-per-lane stream (MI355X_MICROARCH.md, HBM)
+        pmc = json.load(open(pmc_path)).get(hbm_families.get(dom, ""), None)
+        if pmc:
+            traffic = (2.0 * pmc["fetch_kb_per_launch"] + pmc["write_kb_per_launch"]) * 1024.0
     roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None, "avg_launch_ms": pv["ms"] / max(pv["launches"], 1), "alg_bytes_per_launch": pv["bytes"] / max(pv["launches"], 1),
-                "note": "algorithmic bytes (96*S binary / 192*S hadamard+ip per table, DESIGN.md) / HIP-event time of that kernel family; "
-                        "G1 kernels (msm_*) are integer-VALU bound, see 'kernels' shares"}
+                "traffic": traffic, "avg_launch_ms": pv["ms"] / max(pv["launches"], 1), "alg_bytes_per_launch": pv["bytes"] / max(pv["launches"], 1),
+                "note": "this family is classified HBM-streaming (96*S bytes binary / 192*S ip+hadamard per table) but measures integer-VALU bound: "
+                        ">= 7 Fr Montgomery products (136 MACs each) per 96 B; see valu_roofline"}
+    # integer-VALU view of the same kernel and of the G1 (MSM) kernels: 32x32->64 MACs per second against the
+    # measured v_mad_u64_u32 issue rate (tools/instr_rate.hip: 34 T lane-MAC/s at 8 waves/SIMD)
+    FR_MACS, FP_MACS = 136, 300
+    macs = None
+    if dom.startswith("sumcheck_"):
+        per_pair = {"sumcheck_bin_round": 8, "sumcheck_hp_round": 9, "sumcheck_ip_round": 6}[dom] * FR_MACS
+        bytes_per_pair = 96 if dom == "sumcheck_bin_round" else 192
+        macs = pv["bytes"] / bytes_per_pair * per_pair
+    valu = {"kernel": dom, "peak_TMACps": 34.0, "achieved_TMACps": (macs / pv["ms"] / 1e9) if macs else None}
+    if "msm_accum" in prof:
+        items = prof["msm_accum"]["bytes"] / 100.0          # ZK_LAUNCH passes 100 B per (pair, window) item
+        valu["msm_accum_TMACps"] = items * 11 * FP_MACS / prof["msm_accum"]["ms"] / 1e9   # 11 Fp products per mixed add
+        valu["msm_pairs_per_s_prove"] = sum(1 for _ in [0]) and (items / 26.0) / (sum(prof[k]["ms"] for k in prof if k.startswith("msm_") or k == "g1_canonicalise") / 1e3)
+    roofline["valu_roofline"] = valu
 
     out = {"metric": "proving ms/example (batch 256) on 18M-param MLP", "value": value, "unit": "ms/example", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (Fr) / u32x12 (Fp) limbs",
