@@ -12,6 +12,7 @@ ranks, exactly K steps between barriers.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mlp18m_b256|mlp18m_b1|tiny]
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -244,12 +245,18 @@ def main():
     for i in range(args.warmup):
         step(-1 - i)
     barrier()
+    # keep the collector out of the timed region: a generation-2 pass over torch's object graph costs ~40 ms,
+    # i.e. several whole proofs (seen as a one-off stall inside pure host code)
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     t_enq = time.perf_counter() - t0          # host time to enqueue K steps (no device wait inside)
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

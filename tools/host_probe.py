@@ -1,37 +1,35 @@
 #!/usr/bin/env python3
-"""Where does the host time of one proving step go?  (python challenge generation vs C-ABI calls)"""
-import os, sys, time, cProfile, pstats
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-import bench
+"""Host-side time of each prove call of the bench workload (no device wait inside the calls)."""
+import sys, time
+sys.path.insert(0, ".")
+import torch  # noqa: F401  (loads the HIP runtime first, like bench.py)
 from zkdl_amd.capi import Zk
+import bench
 zk = Zk(0)
-wl = bench.Workload(zk, bench.MLP18M, 256, 0)
-for i in range(2):
-    wl.prove(wl.challenges(i)); wl.tr.flush(); zk.sync()
-t0 = time.perf_counter(); ch = [wl.challenges(10 + i) for i in range(5)]; t1 = time.perf_counter()
-print("challenges: %.2f ms/step" % ((t1 - t0) * 200))
-zk.sync()
-t0 = time.perf_counter()
-for c in ch:
-    wl.prove(c); wl.tr.flush()
-t1 = time.perf_counter(); zk.sync(); t2 = time.perf_counter()
-print("prove+flush enqueue: %.2f ms/step ; drain after: %.2f ms total" % ((t1 - t0) * 200, (t2 - t1) * 1e3))
-# per-call timing
-import collections
-acc = collections.Counter()
-for c in ch[:2]:
+dims, batch = bench.WORKLOADS["mlp18m_b256"]
+wl = bench.Workload(zk, dims, batch, seed=0)
+L = len(wl.shapes)
+import os
+for it in range(int(os.environ.get('ITERS','4'))):
+    t0 = time.perf_counter()
+    chal = wl.challenges(it)
+    t1 = time.perf_counter()
     wl.tr.reset()
-    L = len(wl.shapes)
-    for kind, i, cc in c:
-        t = time.perf_counter()
+    rows = []
+    for kind, i, ch in chal:
+        a = time.perf_counter()
         if kind == "fc":
             x_in = wl.A[i - 1] if i > 0 else wl.X
             z_out = wl.Yhat if i == L - 1 else wl.Z[i]
-            wl.fcs[i].prove(x_in, z_out, wl.gens[i], cc[0], cc[1], cc[2], wl.tr)
+            wl.fcs[i].prove(x_in, z_out, wl.gens[i], ch[0], ch[1], ch[2], wl.tr)
         else:
-            wl.relus[i].prove(wl.Z[i], wl.A[i], cc, wl.tr)
-        acc[kind] += time.perf_counter() - t
-    t = time.perf_counter(); wl.tr.flush(); acc["flush"] += time.perf_counter() - t
+            wl.relus[i].prove(wl.Z[i], wl.A[i], ch, wl.tr)
+        rows.append((kind, i, (time.perf_counter() - a) * 1e3))
+    t2 = time.perf_counter()
+    wl.tr.flush()
+    t3 = time.perf_counter()
     zk.sync()
-print({k: round(v * 500, 2) for k, v in acc.items()}, "ms/step")
+    t4 = time.perf_counter()
+    worst = max(rows, key=lambda r: r[2])
+    print(f"iter {it}: worst call {worst[0]}{worst[1]} {worst[2]:.2f} ms; challenges {1e3*(t1-t0):.2f} ms, prove calls {1e3*(t2-t1):.2f} ms, flush enqueue {1e3*(t3-t2):.2f} ms, drain {1e3*(t4-t3):.2f} ms, total {1e3*(t4-t0):.2f}")
+print(" ".join(f"{k}{i}:{ms:.2f}" for k, i, ms in rows))

@@ -37,12 +37,34 @@ static inline Fr load_fr(const zk_fr* h) {
 }
 
 void* zk_ctx::stage_put(const void* src, size_t bytes) {
+  // The ring is cut into STAGE_SEGS segments.  Leaving a segment records an event on every stream that can
+  // have consumed it (main + lanes); re-entering it STAGE_SEGS-1 segments later waits on those events, which
+  // by then have long completed, so steady-state proving never blocks the host here.
   size_t need = (bytes + 63) & ~(size_t)63;
-  if (need > stage_cap) return nullptr;
-  if (stage_off + need > stage_cap) {
-    // ring wrapped: everything staged so far (on any lane) must have been consumed
-    if (hipDeviceSynchronize() != hipSuccess) return nullptr;
-    stage_off = 0;
+  const size_t seg_size = stage_cap / STAGE_SEGS;
+  if (need > seg_size) return nullptr;
+  size_t seg = stage_off / seg_size;
+  if (stage_off + need > (seg + 1) * seg_size) {
+    auto& evs = stage_events[seg];
+    size_t e = 0;
+    auto mark = [&](hipStream_t st) {
+      if (e == evs.size()) {
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
+        evs.push_back(ev);
+      }
+      return hipEventRecord(evs[e++], st) == hipSuccess;
+    };
+    if (!mark(main_stream)) return nullptr;
+    for (auto& l : lanes)
+      if (!mark(l.stream)) return nullptr;
+    if (g1_lane.stream && !mark(g1_lane.stream)) return nullptr;
+    stage_marked[seg] = e;
+    seg = (seg + 1) % STAGE_SEGS;
+    for (size_t q = 0; q < stage_marked[seg]; q++)
+      if (hipEventSynchronize(stage_events[seg][q]) != hipSuccess) return nullptr;
+    stage_marked[seg] = 0;
+    stage_off = seg * seg_size;
   }
   void* dst = stage + stage_off;
   memcpy(dst, src, bytes);
@@ -98,8 +120,11 @@ int zk_ctx_create(int device, zk_ctx** out) {
         ctx->lanes.clear();  // no lanes: everything stays on the main stream
         break;
       }
+    if (!ctx->lanes.empty() &&
+        (hipStreamCreateWithFlags(&ctx->g1_lane.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->g1_lane.done, hipEventDisableTiming) != hipSuccess))
+      ctx->g1_lane.stream = nullptr;
   }
-  ctx->stage_cap = 4u << 20;
+  ctx->stage_cap = 16u << 20;
   if (hipHostMalloc((void**)&ctx->stage, ctx->stage_cap, hipHostMallocDefault) != hipSuccess) {
     delete ctx;
     return ZK_ERR_ALLOC;
@@ -117,10 +142,14 @@ int zk_ctx_destroy(zk_ctx* ctx) {
     if (l.stream) (void)hipStreamDestroy(l.stream);
     if (l.done) (void)hipEventDestroy(l.done);
   }
+  if (ctx->g1_lane.stream) (void)hipStreamDestroy(ctx->g1_lane.stream);
+  if (ctx->g1_lane.done) (void)hipEventDestroy(ctx->g1_lane.done);
   (void)hipEventDestroy(ctx->fork_ev);
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   (void)hipEventDestroy(ctx->t0);
   (void)hipEventDestroy(ctx->t1);
+  for (auto& evs : ctx->stage_events)
+    for (auto e : evs) (void)hipEventDestroy(e);
   (void)hipHostFree(ctx->stage);
   ctx->pool_destroy();
   (void)hipStreamDestroy(ctx->main_stream);
@@ -466,6 +495,7 @@ int zk_set_flag(zk_ctx* ctx, const char* name, int value) {
   CHECK_HOST(ctx, name);
   if (!strcmp(name, "relu_packed")) ctx->relu_packed = value != 0;
   else if (!strcmp(name, "lanes")) ctx->lanes_enabled = value != 0;
+  else if (!strcmp(name, "msm_early_jobs")) ctx->msm_early_jobs = value < 0 ? 0u : (uint32_t)value;
   else return ctx->fail(ZK_ERR_ARG, std::string("unknown flag: ") + name);
   return ZK_OK;
 }

@@ -5,6 +5,8 @@
 // enqueued on one HIP stream, all device memory comes from the context's caching allocator (no
 // driver call in steady state), and the host only waits when a value has to cross to it.
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -51,6 +53,9 @@ struct zk_ctx {
   // the caller's host buffer may die right after the call returns, the staged copy may not
   uint8_t* stage = nullptr;
   size_t stage_cap = 0, stage_off = 0;
+  static constexpr size_t STAGE_SEGS = 8;
+  std::vector<hipEvent_t> stage_events[STAGE_SEGS];
+  size_t stage_marked[STAGE_SEGS] = {};
   void* stage_put(const void* src, size_t bytes);  // returns pinned address holding a copy
 
   // ---- device memory: a size-class caching allocator over plain hipMalloc blocks.
@@ -93,6 +98,8 @@ struct zk_ctx {
       return p;
     }
     void* p = nullptr;
+    static const bool trace = getenv("ZKDL_TRACE_ALLOC") != nullptr;
+    if (trace) fprintf(stderr, "[zkdl] pool miss: %zu B (class %zu) pool %p, %zu MiB held\n", bytes, cls, (void*)cur_pool, pool_bytes >> 20);
     if (hipMalloc(&p, cls) != hipSuccess) {
       (void)hipGetLastError();
       return nullptr;
@@ -118,6 +125,7 @@ struct zk_ctx {
     blocks.clear();
     main_pool.free_lists.clear();
     for (auto& l : lanes) l.pool.free_lists.clear();
+    g1_lane.pool.free_lists.clear();
   }
 
   // ---- lanes: worker streams for independent per-layer proofs (zk_fc_prove / zk_relu_prove).
@@ -132,6 +140,8 @@ struct zk_ctx {
     bool dirty = false;
   };
   std::vector<Lane> lanes;
+  Lane g1_lane;                 // early MSM batches run here, overlapping the remaining Fr work
+  uint32_t msm_early_jobs = 0;  // enqueue threshold for an early MSM batch on the G1 lane; 0 = off (measured slower: two batches pay the latency-bound stages twice)
   hipStream_t main_stream = nullptr;
   hipEvent_t fork_ev = nullptr;
   uint32_t next_lane = 0;
@@ -142,6 +152,13 @@ struct zk_ctx {
         (void)hipStreamWaitEvent(main_stream, l.done, 0);
         l.dirty = false;
       }
+    if (g1_lane.dirty) {
+      (void)hipStreamWaitEvent(main_stream, g1_lane.done, 0);
+      g1_lane.dirty = false;
+    }
+    // restart the round-robin: the same call sequence then lands on the same lanes every proof, so each
+    // lane's pool sees the same sizes and stays warm (a shifting assignment kept missing -> hipMalloc stalls)
+    next_lane = 0;
   }
 
   int fail(int code, const std::string& msg) {

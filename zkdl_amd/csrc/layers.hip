@@ -174,7 +174,34 @@ int zk_transcript::flush() {
   ZK_TRY(msm_flush(ctx, &queue));
   if (n_g1 > n_g1_final && ctx->msm_mode == ZK_MSM_PIPPENGER) ZK_TRY(g1_canonicalise_dev(ctx, g1_d + n_g1_final, (uint32_t)(n_g1 - n_g1_final)));
   n_g1_final = n_g1;
+  deferred_keep.clear();  // the G1 lane has been joined: its batches no longer read these scalars
   return ZK_OK;
+}
+
+// Run the MSMs enqueued so far as one batch on the G1 lane.  Their scalar-prep kernels ran on worker
+// lanes, so the G1 stream first waits on every dirty lane's `done` event; the batch then overlaps the
+// Fr work of the layers still to come.  Scratch comes from the G1 lane's own pool; the prepared
+// scalars (owned by worker-lane pools) are only released at the final flush, after the G1 lane is joined.
+int zk_transcript::flush_early() {
+  zk_ctx::Lane& g = ctx->g1_lane;
+  if (!g.stream || queue.jobs.empty() || ctx->stream != ctx->main_stream) return ZK_OK;
+  (void)hipEventRecord(ctx->fork_ev, ctx->main_stream);
+  (void)hipStreamWaitEvent(g.stream, ctx->fork_ev, 0);
+  for (auto& l : ctx->lanes)
+    if (l.dirty) (void)hipStreamWaitEvent(g.stream, l.done, 0);
+  ctx->stream = g.stream;
+  ctx->cur_pool = &g.pool;
+  int rc = msm_run_jobs(ctx, queue.jobs, queue.c);
+  if (rc == ZK_OK && n_g1 > n_g1_final) rc = g1_canonicalise_dev(ctx, g1_d + n_g1_final, (uint32_t)(n_g1 - n_g1_final));
+  (void)hipEventRecord(g.done, g.stream);
+  g.dirty = true;
+  ctx->stream = ctx->main_stream;
+  ctx->cur_pool = &ctx->main_pool;
+  n_g1_final = n_g1;
+  queue.jobs.clear();
+  for (auto& b : queue.keep) deferred_keep.push_back(std::move(b));
+  queue.keep.clear();
+  return rc;
 }
 
 // ------------------------------------------------------------------ zkFC
@@ -216,8 +243,17 @@ int fc_forward(zk_ctx* ctx, const zk_fc* fc, const Fr* x, uint32_t xn, Fr* z) {
 }
 
 // zkFC::prove, zkfc.cu:128-145
+static int fc_prove_lane(zk_ctx* ctx, zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint32_t zn, zk_gens* gens,
+                         const zk_fr* u_bs_h, const zk_fr* u_in_h, const zk_fr* u_out_h, zk_transcript* tr);
 int fc_prove(zk_ctx* ctx, zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint32_t zn, zk_gens* gens,
              const zk_fr* u_bs_h, const zk_fr* u_in_h, const zk_fr* u_out_h, zk_transcript* tr) {
+  ZK_TRY(fc_prove_lane(ctx, fc, x, xn, z, zn, gens, u_bs_h, u_in_h, u_out_h, tr));
+  // enough MSMs queued: start them now on the G1 lane, under the Fr work of the remaining layers
+  if (ctx->msm_early_jobs && ctx->lanes_enabled && !ctx->lanes.empty() && tr->queue.jobs.size() >= ctx->msm_early_jobs) return tr->flush_early();
+  return ZK_OK;
+}
+static int fc_prove_lane(zk_ctx* ctx, zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint32_t zn, zk_gens* gens,
+                         const zk_fr* u_bs_h, const zk_fr* u_in_h, const zk_fr* u_out_h, zk_transcript* tr) {
   const uint32_t n_gens = gens->n;
   if (xn % fc->in != 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions 1");
   const uint32_t batch = xn / fc->in;

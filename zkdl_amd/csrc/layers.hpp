@@ -63,7 +63,9 @@ struct zk_transcript {  // proof values in the order of SURVEY.md App. A.6, resi
   zk::MsmQueue queue;      // deferred MSMs whose results land in g1_d
   size_t n_g1_final = 0;   // G1 entries already flushed + canonicalised
   int ensure(size_t add_fr, size_t add_g1);
+  std::vector<zk::DBuf<zk::Fr>> deferred_keep;  // scalars of early batches, released at the final flush
   int flush();             // run pending MSMs, canonicalise their outputs
+  int flush_early();       // run the MSMs queued so far on the G1 lane (no host wait, no main-stream wait)
 };
 
 namespace zk {
@@ -77,6 +79,7 @@ int gens_table(zk_ctx* ctx, zk_gens* g, uint32_t c, uint32_t W, const G1Table** 
 int msm_batch_dev(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_unmont, bool probe_bits, G1J* out);
 int msm_enqueue(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_unmont, bool probe_bits, G1J* out, MsmQueue* queue);
 int msm_flush(zk_ctx* ctx, MsmQueue* queue);
+int msm_run_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs, uint32_t c);
 int g1_canonicalise_dev(zk_ctx* ctx, G1J* pts, uint32_t n);
 int commit_dev(zk_ctx* ctx, zk_gens* gens, const Fr* t, uint32_t tn, G1J* out);
 // queue == nullptr: run now; otherwise (PIPPENGER back end) the MSMs are deferred to msm_flush(queue)

@@ -452,7 +452,7 @@ int msm_enqueue(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_
   return ZK_OK;
 }
 
-int msm_flush(zk_ctx* ctx, MsmQueue* queue) {
+int msm_flush(zk_ctx* ctx, MsmQueue* queue) {  // on the current stream; releases the prepared scalars
   if (queue->jobs.empty()) return ZK_OK;
   int rc = msm_run_jobs(ctx, queue->jobs, queue->c);
   queue->jobs.clear();

@@ -21,6 +21,7 @@
 //
 // A length-2^24 binary sumcheck is 1 + 14 + 1 launches instead of the reference's ~2000.  Fr results
 // are canonical, so this re-association is bit-identical to the reference's order.
+#include <cstdlib>
 #include "ctx.hpp"
 #include "dev_util.hpp"
 
@@ -59,61 +60,95 @@ __global__ void __launch_bounds__(256) k_sc_prep(const Fr* __restrict__ w, uint3
   }
 }
 
-// One big sumcheck round (see file header).  x = fold challenge of this round, read from device memory.
-template <int MODE>
+// R consecutive big sumcheck rounds in one launch (R = 1, 2 or 3).  All challenges are known up front, so
+// a lane can take 2^R consecutive elements, emit the coefficient terms of round r0 for its 2^(R-1) pairs,
+// fold them, emit round r0+1 for the 2^(R-2) folded pairs, ... entirely in registers, and write only the
+// table after R folds: R times fewer launches and (1 + 2^-R) instead of R*1.5 table passes over HBM.
+// Missing elements (ragged sizes) read as zero, which reproduces Fr_me_step's odd-tail rule
+// a0 - x*a0 = a0 + x*(0 - a0) and Fr_ip_sc_step's zero padding (proof.cu:61-64) exactly.
+//   fold[r0 + j]  : fold challenge of round r0 + j (device memory)
+//   Aj / cj       : low weight table and its width for round r0 + j ; B the fixed high table
+//   partial[blk*3R + 3j + q], j < R, q < 3 ; prev_* : the previous launch's partials (3*prev_R per block)
+static uint32_t sc_multi_threshold(int R) {
+  static const uint32_t t3 = [] { const char* e = getenv("ZKDL_SC_R3_MIN"); return e ? (uint32_t)strtoul(e, nullptr, 0) : (1u << 22); }();
+  static const uint32_t t2 = [] { const char* e = getenv("ZKDL_SC_R2_MIN"); return e ? (uint32_t)strtoul(e, nullptr, 0) : (1u << 21); }();
+  return R == 3 ? t3 : t2;
+}
+
+struct ScLevels {
+  const Fr* A[3];
+  uint32_t c[3];
+};
+template <int MODE, int R>
 __global__ void __launch_bounds__(256) k_sc_round(const Fr* __restrict__ a, const Fr* __restrict__ b, Fr* __restrict__ a_out, Fr* __restrict__ b_out,
-                                                   const Fr* __restrict__ xp, const Fr* __restrict__ A, const Fr* __restrict__ B, uint32_t c,
-                                                   uint32_t in_size, uint32_t out_size, Fr* __restrict__ partial,
-                                                   const Fr* __restrict__ prev_partial, uint32_t prev_blocks, Fr* __restrict__ prev_dst) {
+                                                   const Fr* __restrict__ fold, ScLevels lv, const Fr* __restrict__ B, uint32_t in_size, uint32_t out_size,
+                                                   Fr* __restrict__ partial, const Fr* __restrict__ prev_partial, uint32_t prev_blocks, uint32_t prev_cols,
+                                                   Fr* __restrict__ prev_dst) {
   __shared__ Fr lds[4];
-  const Fr x = *xp;
-  const uint32_t mask = (1u << c) - 1u;
-  Fr s0 = fr_zero(), s1 = fr_zero(), s2 = fr_zero();
+  constexpr int NE = 1 << R;
+  Fr x[R];
+#pragma clang loop unroll(full)
+  for (int j = 0; j < R; j++) x[j] = fold[j];
+  Fr acc[3 * R];
+#pragma clang loop unroll(full)
+  for (int i = 0; i < 3 * R; i++) acc[i] = fr_zero();
   for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < out_size; g += gridDim.x * blockDim.x) {
-    const uint32_t g0 = 2 * g, g1 = 2 * g + 1;
-    Fr a0 = a[g0];  // g0 < in_size always holds for g < out_size
-    Fr a1 = g1 < in_size ? a[g1] : fr_zero();
-    Fr da = fr_sub(a1, a0);
-    Fr c0, c1, c2;
-    if (MODE == SC_BIN) {
-      c0 = fr_sub(fr_sqr(a0), a0);
-      c1 = fr_sub(fr_mul(fr_dbl(a0), da), da);
-      c2 = fr_sqr(da);
-    } else {
-      Fr b0 = b[g0];
-      Fr b1 = g1 < in_size ? b[g1] : fr_zero();
-      Fr db = fr_sub(b1, b0);
-      c0 = fr_mul(a0, b0);
-      c1 = fr_add(fr_mul(a0, db), fr_mul(b0, da));
-      c2 = fr_mul(da, db);
-      b_out[g] = g1 < in_size ? fr_add(b0, fr_mul(x, db)) : fr_sub(b0, fr_mul(x, b0));  // Fr_me_step incl. odd tail
+    Fr va[NE], vb[MODE == SC_BIN ? 1 : NE];
+    const uint64_t base = (uint64_t)g * NE;
+#pragma clang loop unroll(full)
+    for (int e = 0; e < NE; e++) {
+      va[e] = base + e < in_size ? a[base + e] : fr_zero();
+      if (MODE != SC_BIN) vb[e] = base + e < in_size ? b[base + e] : fr_zero();
     }
-    a_out[g] = g1 < in_size ? fr_add(a0, fr_mul(x, da)) : fr_sub(a0, fr_mul(x, a0));
-    if (MODE != SC_IP) {
-      Fr w = fr_mul(A[g & mask], B[g >> c]);
-      c0 = fr_mul(c0, w);
-      c1 = fr_mul(c1, w);
-      c2 = fr_mul(c2, w);
+#pragma clang loop unroll(full)
+    for (int j = 0; j < R; j++) {
+      const int np = NE >> (j + 1);  // pairs of this lane in round r0 + j
+      const uint32_t mask = (1u << lv.c[j]) - 1u;
+#pragma clang loop unroll(full)
+      for (int i = 0; i < np; i++) {
+        const uint32_t h = g * np + i;  // pair index within the round
+        Fr a0 = va[2 * i], a1 = va[2 * i + 1];
+        Fr da = fr_sub(a1, a0);
+        Fr c0, c1, c2;
+        if (MODE == SC_BIN) {
+          c0 = fr_sub(fr_sqr(a0), a0);
+          c1 = fr_sub(fr_mul(fr_dbl(a0), da), da);
+          c2 = fr_sqr(da);
+        } else {
+          Fr b0 = vb[2 * i], b1 = vb[2 * i + 1];
+          Fr db = fr_sub(b1, b0);
+          c0 = fr_mul(a0, b0);
+          c1 = fr_add(fr_mul(a0, db), fr_mul(b0, da));
+          c2 = fr_mul(da, db);
+          vb[i] = fr_add(b0, fr_mul(x[j], db));
+        }
+        va[i] = fr_add(a0, fr_mul(x[j], da));
+        if (MODE != SC_IP) {
+          Fr w = fr_mul(lv.A[j][h & mask], B[h >> lv.c[j]]);
+          c0 = fr_mul(c0, w);
+          c1 = fr_mul(c1, w);
+          c2 = fr_mul(c2, w);
+        }
+        acc[3 * j + 0] = fr_add(acc[3 * j + 0], c0);
+        acc[3 * j + 1] = fr_add(acc[3 * j + 1], c1);
+        acc[3 * j + 2] = fr_add(acc[3 * j + 2], c2);
+      }
     }
-    s0 = fr_add(s0, c0);
-    s1 = fr_add(s1, c1);
-    s2 = fr_add(s2, c2);
+    a_out[g] = va[0];
+    if (MODE != SC_BIN) b_out[g] = vb[0];
   }
-  s0 = block_sum_fr(s0, lds);
-  s1 = block_sum_fr(s1, lds);
-  s2 = block_sum_fr(s2, lds);
-  if (threadIdx.x == 0) {
-    partial[3 * blockIdx.x + 0] = s0;
-    partial[3 * blockIdx.x + 1] = s1;
-    partial[3 * blockIdx.x + 2] = s2;
+#pragma clang loop unroll(full)
+  for (int i = 0; i < 3 * R; i++) {
+    Fr t = block_sum_fr(acc[i], lds);
+    if (threadIdx.x == 0) partial[(uint64_t)blockIdx.x * (3 * R) + i] = t;
   }
-  // workgroup 0 also closes the previous round: its partials were completed by the previous launch
+  // workgroup 0 also closes the previous launch: its partials were completed by the kernel boundary
   if (blockIdx.x == 0 && prev_blocks) {
-    for (uint32_t q = 0; q < 3; q++) {
-      Fr acc = fr_zero();
-      for (uint32_t i = threadIdx.x; i < prev_blocks; i += blockDim.x) acc = fr_add(acc, prev_partial[3 * i + q]);
-      acc = block_sum_fr(acc, lds);
-      if (threadIdx.x == 0) prev_dst[q] = acc;
+    for (uint32_t q = 0; q < prev_cols; q++) {
+      Fr t = fr_zero();
+      for (uint32_t i = threadIdx.x; i < prev_blocks; i += blockDim.x) t = fr_add(t, prev_partial[(uint64_t)i * prev_cols + q]);
+      t = block_sum_fr(t, lds);
+      if (threadIdx.x == 0) prev_dst[q] = t;
     }
   }
 }
@@ -124,7 +159,7 @@ __global__ void __launch_bounds__(256) k_sc_round(const Fr* __restrict__ a, cons
 template <int MODE>
 __global__ void __launch_bounds__(512) k_sc_tail(const Fr* __restrict__ a_in, const Fr* __restrict__ b_in, uint32_t n, const Fr* __restrict__ fold,
                                                   const Fr* __restrict__ w, uint32_t k, uint32_t r0, Fr* __restrict__ proof,
-                                                  const Fr* __restrict__ prev_partial, uint32_t prev_blocks, Fr* __restrict__ prev_dst) {
+                                                  const Fr* __restrict__ prev_partial, uint32_t prev_blocks, uint32_t prev_cols, Fr* __restrict__ prev_dst) {
   extern __shared__ Fr sm[];
   Fr* ta = sm;                                              // SC_TAIL_N
   Fr* tb = sm + SC_TAIL_N;                                  // SC_TAIL_N (unused for SC_BIN)
@@ -132,9 +167,9 @@ __global__ void __launch_bounds__(512) k_sc_tail(const Fr* __restrict__ a_in, co
   Fr* red = E + SC_TAIL_N / 2;                              // 8 reduction slots
   const uint32_t tid = threadIdx.x;
   if (prev_blocks) {
-    for (uint32_t q = 0; q < 3; q++) {
+    for (uint32_t q = 0; q < prev_cols; q++) {
       Fr acc = fr_zero();
-      for (uint32_t i = tid; i < prev_blocks; i += blockDim.x) acc = fr_add(acc, prev_partial[3 * i + q]);
+      for (uint32_t i = tid; i < prev_blocks; i += blockDim.x) acc = fr_add(acc, prev_partial[(uint64_t)i * prev_cols + q]);
       acc = block_sum_fr(acc, red);
       if (tid == 0) prev_dst[q] = acc;
     }
@@ -229,7 +264,7 @@ static int run_sumcheck(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n,
   DBuf<Fr> abuf, bbuf, partial, tabA, tabB;
   uint32_t s = 0;
   if (nbig) {
-    if (!abuf.alloc(ctx, (size_t)half + (half + 1) / 2 + 2) || (two && !bbuf.alloc(ctx, (size_t)half + (half + 1) / 2 + 2)) || !partial.alloc(ctx, 2 * 3 * SC_MAX_BLOCKS))
+    if (!abuf.alloc(ctx, (size_t)half + (half + 1) / 2 + 2) || (two && !bbuf.alloc(ctx, (size_t)half + (half + 1) / 2 + 2)) || !partial.alloc(ctx, 2 * 9 * SC_MAX_BLOCKS))
       return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: sumcheck tables");
     if (MODE != SC_IP) {
       // fixed split: every big round r (< nbig) needs c_r = s - 1 - r >= 0
@@ -243,29 +278,54 @@ static int run_sumcheck(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n,
   const Fr* a = a_in;
   const Fr* b = b_in;
   uint32_t sz = n;
+  const uint32_t slot_elems = (half + 3) / 2 + 2;   // a launch of R >= 1 rounds writes <= ceil(n/2) elements; later ones less
+  (void)slot_elems;
   Fr* a_slots[2] = {abuf.get(), abuf.get() ? abuf.get() + half + 1 : nullptr};
   Fr* b_slots[2] = {bbuf.get(), bbuf.get() ? bbuf.get() + half + 1 : nullptr};
   const char* tag = MODE == SC_IP ? "sumcheck_ip_round" : MODE == SC_HP ? "sumcheck_hp_round" : "sumcheck_bin_round";
   const Fr* prev_partial = nullptr;
-  uint32_t prev_blocks = 0;
+  uint32_t prev_blocks = 0, prev_cols = 0;
   Fr* prev_dst = nullptr;
-  for (uint32_t r = 0; r < nbig; r++) {
-    uint32_t osz = (sz + 1) / 2;
-    uint32_t c = MODE == SC_IP ? 0 : s - 1 - r;
-    const Fr* Ar = MODE == SC_IP ? nullptr : tabA.get() + ((1u << s) - (1u << (s - r)));
+  uint32_t launch = 0;
+  for (uint32_t r = 0; r < nbig;) {
+    // Folding R rounds in one lane divides the lane count by 2^R: only worth it while the launch still
+    // fills the chip (thresholds measured on MI355X, overridable for sweeps).
+    uint32_t R = 1;
+    if (sz >= sc_multi_threshold(3)) R = 3;
+    else if (sz >= sc_multi_threshold(2)) R = 2;
+    if (R > nbig - r) R = nbig - r;
+    uint32_t osz = sz;
+    for (uint32_t j = 0; j < R; j++) osz = (osz + 1) / 2;
+    ScLevels lv;
+    for (uint32_t j = 0; j < 3; j++) {
+      lv.A[j] = nullptr;
+      lv.c[j] = 0;
+      if (MODE != SC_IP && j < R) {
+        lv.c[j] = s - 1 - (r + j);
+        lv.A[j] = tabA.get() + ((1u << s) - (1u << (s - (r + j))));
+      }
+    }
     uint32_t grid = stream_grid(osz, 256, SC_MAX_BLOCKS);
-    Fr* ao = a_slots[r & 1];
-    Fr* bo = b_slots[r & 1];
-    Fr* part = partial.get() + (r & 1) * 3 * SC_MAX_BLOCKS;
+    Fr* ao = a_slots[launch & 1];
+    Fr* bo = b_slots[launch & 1];
+    Fr* part = partial.get() + (launch & 1) * 9 * SC_MAX_BLOCKS;
     uint64_t bytes = (two ? 2ull : 1ull) * 32ull * ((uint64_t)sz + osz);
-    ZK_LAUNCH(ctx, tag, bytes, k_sc_round<MODE>, dim3(grid), dim3(256), 0, a, b, ao, bo, fold_d + r, Ar, (const Fr*)tabB.get(), c, sz, osz, part, prev_partial, prev_blocks,
-              prev_dst);
+#define ZK_SC_LAUNCH(RR)                                                                                                                                   \
+  ZK_LAUNCH(ctx, tag, bytes, (k_sc_round<MODE, RR>), dim3(grid), dim3(256), 0, a, b, ao, bo, fold_d + r, lv, (const Fr*)tabB.get(), sz, osz, part, prev_partial, \
+            prev_blocks, prev_cols, prev_dst)
+    if (R == 3) ZK_SC_LAUNCH(3);
+    else if (R == 2) ZK_SC_LAUNCH(2);
+    else ZK_SC_LAUNCH(1);
+#undef ZK_SC_LAUNCH
     prev_partial = part;
     prev_blocks = grid;
+    prev_cols = 3 * R;
     prev_dst = proof_d + 3 * r;
     a = ao;
     b = bo;
     sz = osz;
+    r += R;
+    launch++;
   }
   size_t lds = ((MODE == SC_BIN ? 1 : 2) * SC_TAIL_N + SC_TAIL_N / 2 + 8) * sizeof(Fr);
   static bool lds_attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in on some runtimes
@@ -275,7 +335,7 @@ static int run_sumcheck(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n,
     lds_attr_set = true;
   }
   const char* ttag = MODE == SC_IP ? "sumcheck_ip_tail" : MODE == SC_HP ? "sumcheck_hp_tail" : "sumcheck_bin_tail";
-  ZK_LAUNCH(ctx, ttag, (two ? 2ull : 1ull) * 32ull * sz, k_sc_tail<MODE>, dim3(1), dim3(512), lds, a, b, sz, fold_d, weight_d, k, nbig, proof_d, prev_partial, prev_blocks, prev_dst);
+  ZK_LAUNCH(ctx, ttag, (two ? 2ull : 1ull) * 32ull * sz, k_sc_tail<MODE>, dim3(1), dim3(512), lds, a, b, sz, fold_d, weight_d, k, nbig, proof_d, prev_partial, prev_blocks, prev_cols, prev_dst);
   return ZK_OK;
 }
 
