@@ -91,7 +91,8 @@ class Workload:
         self.Yhat = zk.fr_unmont(self.fcs[L - 1].forward(cur))                   # demo.cu:119
         zk.sync()
         t_fwd = time.perf_counter() - t0
-        self.tr = Transcript(zk)
+        self.trs = [Transcript(zk), Transcript(zk)]   # alternated: proof i's G1 phase runs under proof i+1's Fr phase
+        self.tr = self.trs[0]
         self.info = dict(setup_generators_s=t_gen, setup_commit_s=t_commit, commit_pairs=pairs,
                          commit_mops=pairs / t_commit / 1e6, inference_s=t_fwd)
         # algorithmic Fr bytes of one proof: sumcheck 96*S (binary) / 192*S (ip, hadamard),
@@ -124,17 +125,18 @@ class Workload:
             out.append(("fc", i, fc(sh[i])))
         return out
 
-    def prove(self, chal):
-        """The reference's timed region, enqueued on the library's stream (no host sync inside)."""
+    def prove(self, chal, tr=None):
+        """The reference's timed region, enqueued on the library's streams (no host sync inside)."""
         L = len(self.shapes)
-        self.tr.reset()
+        tr = tr or self.tr
+        tr.reset()
         for kind, i, ch in chal:
             if kind == "fc":
                 x_in = self.A[i - 1] if i > 0 else self.X
                 z_out = self.Yhat if i == L - 1 else self.Z[i]
-                self.fcs[i].prove(x_in, z_out, self.gens[i], ch[0], ch[1], ch[2], self.tr)
+                self.fcs[i].prove(x_in, z_out, self.gens[i], ch[0], ch[1], ch[2], tr)
             else:
-                self.relus[i].prove(self.Z[i], self.A[i], ch, self.tr)
+                self.relus[i].prove(self.Z[i], self.A[i], ch, tr)
 
 
 from zkdl_amd.dist import lanes_to_fr  # noqa: E402
@@ -195,6 +197,7 @@ def main():
     ap.add_argument("--workload", default="mlp18m_b256", choices=sorted(WORKLOADS))
     ap.add_argument("--msm", default="pippenger", choices=["pippenger", "literal"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="finish every proof on the main stream (no overlap of proof i's G1 phase with proof i+1's Fr phase)")
     ap.add_argument("--backend", default=os.environ.get("BENCH_BACKEND", "nccl"), help="nccl (= RCCL, default) | gloo (rehearsal on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses device 0")
     args = ap.parse_args()
@@ -222,18 +225,24 @@ def main():
     dims, batch = WORKLOADS[args.workload]
     wl = Workload(zk, dims, batch, seed=rank)
 
-    stream_ptr = zk.lib.zk_ctx_stream(zk.ctx)
+    # The G1 phase of every proof (MSM batch, canonicalisation, digest) and the all-reduce of its digest are
+    # ordered on the library's G1 stream; the Fr phase of the next proof runs beside them on the worker lanes.
+    pipelined = not args.no_pipeline
+    stream_ptr = zk.lib.zk_ctx_g1_stream(zk.ctx) if pipelined else zk.lib.zk_ctx_stream(zk.ctx)
     ext = torch.cuda.ExternalStream(stream_ptr, device=torch.device("cuda", local_rank))
     agg = torch.zeros(8, dtype=torch.int64, device="cuda")
-    own = torch.zeros(8, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
 
     def step(i):
         chal = wl.challenges(i)
-        wl.prove(chal)
-        wl.tr.digest_dev(agg.data_ptr())
+        tr = wl.trs[i & 1] if pipelined else wl.tr
+        wl.prove(chal, tr)
+        if pipelined:
+            tr.seal(agg.data_ptr())
+        else:
+            tr.digest_dev(agg.data_ptr())
         if world > 1:
             with torch.cuda.stream(ext):
-                own.copy_(agg, non_blocking=True)
                 dist.all_reduce(agg, op=dist.ReduceOp.SUM)      # RCCL over xGMI: 8 x uint64 lanes
 
     def barrier():

@@ -47,11 +47,15 @@ def synth_mlp(orc, dims, batch, seed=0, gens=None):
         k = ceil_log2(B_p * s["out_p"])
         return [rand_fr(rng, k + 5), rand_fr(rng, k + 5), rand_fr(rng, k + 4), rand_fr(rng, k + 4), rand_fr(rng, k), rand_fr(rng, k), rand_fr(rng, k)]
 
-    chal.append(("fc", L - 1, fc_ch(shapes[L - 1])))
-    for i in range(L - 2, -1, -1):
-        chal.append(("relu", i, relu_ch(shapes[i])))
-        chal.append(("fc", i, fc_ch(shapes[i])))
-    return dict(dims=dims, batch=batch, B_p=B_p, shapes=shapes, W=W, X=X, gens=gens, chal=chal)
+    def draw():
+        out = [("fc", L - 1, fc_ch(shapes[L - 1]))]
+        for i in range(L - 2, -1, -1):
+            out.append(("relu", i, relu_ch(shapes[i])))
+            out.append(("fc", i, fc_ch(shapes[i])))
+        return out
+
+    chal = draw()
+    return dict(dims=dims, batch=batch, B_p=B_p, shapes=shapes, W=W, X=X, gens=gens, chal=chal, draw_chal=draw)
 
 
 def prove_mlp_oracle(orc, model):
@@ -81,11 +85,10 @@ def prove_mlp_oracle(orc, model):
     return np.concatenate(frs), np.concatenate(g1s)
 
 
-def prove_mlp_gpu(zk, model, gens_dev=None, timed=False):
-    """Returns (Fr transcript, affine G1 transcript, inf flags, info)."""
-    from zkdl_amd.capi import FC, ReLU, Transcript
+def setup_mlp_gpu(zk, model, gens_dev=None):
+    """Layers, forward pass and commitments on the device; returns the state enqueue_proof() needs."""
+    from zkdl_amd.capi import FC, ReLU
     sh, L = model["shapes"], len(model["shapes"])
-    B_p = model["B_p"]
     gens = gens_dev or [zk.gens(zk.upload(g)) for g in model["gens"]]
     fcs = []
     for i, s in enumerate(sh):
@@ -102,19 +105,32 @@ def prove_mlp_gpu(zk, model, gens_dev=None, timed=False):
         Z.append(z); A.append(a)
         cur = a
     Yhat = zk.fr_unmont(fcs[L - 1].forward(cur))
+    return dict(L=L, gens=gens, fcs=fcs, relus=relus, X=X, Z=Z, A=A, Yhat=Yhat)
+
+
+def enqueue_proof(st, chal, tr):
+    """The prove calls of one proof, in the reference's order (last layer first); nothing is read back."""
+    L = st["L"]
+    for kind, i, ch in chal:
+        if kind == "fc":
+            x_in = (st["A"][i - 1] if i > 0 else st["X"])
+            z_out = st["Yhat"] if i == L - 1 else st["Z"][i]
+            st["fcs"][i].prove(x_in, z_out, st["gens"][i], ch[0], ch[1], ch[2], tr)
+        else:
+            st["relus"][i].prove(st["Z"][i], st["A"][i], ch, tr)
+
+
+def prove_mlp_gpu(zk, model, gens_dev=None, timed=False):
+    """Returns (Fr transcript, affine G1 transcript, inf flags, info)."""
+    from zkdl_amd.capi import Transcript
+    st = setup_mlp_gpu(zk, model, gens_dev)
     tr = Transcript(zk)
     zk.sync()
     if timed:
         zk.timer_start()
-    for kind, i, ch in model["chal"]:
-        if kind == "fc":
-            x_in = (A[i - 1] if i > 0 else X)
-            z_out = Yhat if i == L - 1 else Z[i]
-            fcs[i].prove(x_in, z_out, gens[i], ch[0], ch[1], ch[2], tr)
-        else:
-            relus[i].prove(Z[i], A[i], ch, tr)
+    enqueue_proof(st, model["chal"], tr)
     ms = zk.timer_stop_ms() if timed else None
     fr, _ = tr.read()
     aff, inf = tr.read_affine()
-    info = dict(ms=ms, Yhat=Yhat.download(), coms=[fc.com().download() for fc in fcs], fcs=fcs, relus=relus, tr=tr)
+    info = dict(ms=ms, Yhat=st["Yhat"].download(), coms=[fc.com().download() for fc in st["fcs"]], fcs=st["fcs"], relus=st["relus"], tr=tr, state=st)
     return fr, aff, inf, info

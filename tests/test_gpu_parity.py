@@ -427,3 +427,59 @@ def test_lanes_and_deferred_msm_do_not_change_the_transcript(zk, oracle):
     zk.set_flag("lanes", 1)
     for r in runs[1:]:
         assert eq(r[0], runs[0][0]) and eq(r[1], runs[0][1]) and eq(r[2], runs[0][2]) and eq(r[3], runs[0][3])
+
+
+def test_sealed_transcripts_pipeline_proofs_without_changing_them(zk, oracle):
+    """zk_transcript_seal finishes a proof on the G1 stream while the next proof's Fr phase is already
+    running on the worker lanes (two transcripts alternated, as bench.py does).  Pure scheduling: every
+    proof must equal the one obtained by proving it alone and flushing on the main stream, and the
+    device-side digest lanes must equal the host digest."""
+    import numpy as np
+    from mlp_util import enqueue_proof, setup_mlp_gpu, synth_mlp
+    from zkdl_amd.capi import MSM_PIPPENGER, Transcript
+    from zkdl_amd.dist import lanes_to_fr
+    zk.set_msm_mode(MSM_PIPPENGER)
+    model = synth_mlp(oracle, [16, 32, 24, 8], 4, seed=33)
+    st = setup_mlp_gpu(zk, model)
+    chals = [model["chal"]] + [model["draw_chal"]() for _ in range(4)]
+    # reference runs: one at a time, synchronous flush
+    want = []
+    tr0 = Transcript(zk)
+    for ch in chals:
+        tr0.reset()
+        enqueue_proof(st, ch, tr0)
+        fr, _ = tr0.read()
+        aff, inf = tr0.read_affine()
+        want.append((fr, aff, inf, tr0.digest()))
+    # pipelined: seal, move on to the next proof immediately, read each transcript two proofs later
+    trs = [Transcript(zk), Transcript(zk)]
+    lanes = [zk.empty(2, 8), zk.empty(2, 8)]   # 8 x uint64 digest lanes each (2 x 32 bytes)
+    got = [None] * len(chals)
+
+    def collect(i):
+        tr = trs[i & 1]
+        fr, _ = tr.read()
+        aff, inf = tr.read_affine()
+        l64 = lanes[i & 1].download().reshape(-1).view(np.uint64)
+        got[i] = (fr, aff, inf, l64.copy())
+
+    for i, ch in enumerate(chals):
+        if i >= 2:
+            collect(i - 2)
+        trs[i & 1].reset()
+        enqueue_proof(st, ch, trs[i & 1])
+        trs[i & 1].seal(lanes[i & 1].ptr)
+    collect(len(chals) - 2)
+    collect(len(chals) - 1)
+    for w, g in zip(want, got):
+        assert eq(g[0], w[0]) and eq(g[1], w[1]) and eq(g[2], w[2])
+        d = lanes_to_fr([int(x) for x in g[3]])
+        assert d == int.from_bytes(np.ascontiguousarray(w[3]).tobytes(), "little")
+    # a seal without lanes degrades to the synchronous path with the same values
+    zk.set_flag("lanes", 0)
+    trs[0].reset()
+    enqueue_proof(st, chals[0], trs[0])
+    trs[0].seal(lanes[0].ptr)
+    fr, _ = trs[0].read()
+    zk.set_flag("lanes", 1)
+    assert eq(fr, want[0][0])

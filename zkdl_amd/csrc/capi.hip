@@ -135,7 +135,7 @@ int zk_ctx_create(int device, zk_ctx** out) {
 int zk_ctx_destroy(zk_ctx* ctx) {
   if (!ctx) return ZK_ERR_ARG;
   (void)hipSetDevice(ctx->device);
-  ctx->join_lanes();
+  ctx->join_all();
   (void)hipDeviceSynchronize();
   ctx->prof_flush();
   for (auto& l : ctx->lanes) {
@@ -158,11 +158,13 @@ int zk_ctx_destroy(zk_ctx* ctx) {
 }
 int zk_ctx_sync(zk_ctx* ctx) {
   CHECK_CTX(ctx);
+  ctx->join_all();
   ZK_HIP(ctx, hipStreamSynchronize(ctx->main_stream));
   return ZK_OK;
 }
 const char* zk_last_error(const zk_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
 void* zk_ctx_stream(zk_ctx* ctx) { return ctx ? (void*)ctx->main_stream : nullptr; }
+void* zk_ctx_g1_stream(zk_ctx* ctx) { return ctx ? (void*)(ctx->g1_lane.stream ? ctx->g1_lane.stream : ctx->main_stream) : nullptr; }
 
 int zk_malloc(zk_ctx* ctx, size_t bytes, void** out_d) {
   CHECK_CTX(ctx);
@@ -495,7 +497,6 @@ int zk_set_flag(zk_ctx* ctx, const char* name, int value) {
   CHECK_HOST(ctx, name);
   if (!strcmp(name, "relu_packed")) ctx->relu_packed = value != 0;
   else if (!strcmp(name, "lanes")) ctx->lanes_enabled = value != 0;
-  else if (!strcmp(name, "msm_early_jobs")) ctx->msm_early_jobs = value < 0 ? 0u : (uint32_t)value;
   else return ctx->fail(ZK_ERR_ARG, std::string("unknown flag: ") + name);
   return ZK_OK;
 }
@@ -512,7 +513,7 @@ int zk_gens_create(zk_ctx* ctx, const zk_g1j* gens, uint32_t n, zk_gens** out) {
 }
 int zk_gens_destroy(zk_gens* g) {
   if (!g) return ZK_ERR_ARG;
-  if (g->ctx) g->ctx->join_lanes();
+  if (g->ctx) g->ctx->join_all();  // a sealed proof may still be reading the window tables on the G1 stream
   gens_destroy(g);
   return ZK_OK;
 }
@@ -594,7 +595,7 @@ int zk_fc_from_float(zk_ctx* ctx, uint32_t in, uint32_t out, const float* w, zk_
 }
 int zk_fc_destroy(zk_fc* fc) {
   if (!fc) return ZK_ERR_ARG;
-  if (fc->ctx) fc->ctx->join_lanes();
+  if (fc->ctx) fc->ctx->join_all();
   if (fc->ctx) dev_free(fc->ctx, fc->weights);
   gens_destroy(fc->com);
   delete fc;
@@ -668,6 +669,7 @@ int zk_transcript_destroy(zk_transcript* tr) {
   if (!tr) return ZK_ERR_ARG;
   tr->ctx->join_lanes();
   (void)tr->flush();
+  if (tr->sealed_ev) (void)hipEventDestroy(tr->sealed_ev);
   dev_free(tr->ctx, tr->fr_d);
   dev_free(tr->ctx, tr->g1_d);
   delete tr;
@@ -684,6 +686,11 @@ int zk_transcript_flush(zk_transcript* tr) {
   if (!tr) return ZK_ERR_ARG;
   tr->ctx->join_lanes();
   return tr->flush();
+}
+int zk_transcript_seal(zk_transcript* tr, uint64_t* out8_d) {
+  if (!tr) return ZK_ERR_ARG;
+  if (out8_d && (((uintptr_t)out8_d) & 7u)) return tr->ctx->fail(ZK_ERR_ARG, "misaligned pointer: out8_d");
+  return tr->seal(out8_d);
 }
 int zk_transcript_counts(zk_transcript* tr, size_t* n_fr, size_t* n_g1) {
   if (!tr) return ZK_ERR_ARG;

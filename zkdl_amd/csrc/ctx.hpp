@@ -140,25 +140,31 @@ struct zk_ctx {
     bool dirty = false;
   };
   std::vector<Lane> lanes;
-  Lane g1_lane;                 // early MSM batches run here, overlapping the remaining Fr work
-  uint32_t msm_early_jobs = 0;  // enqueue threshold for an early MSM batch on the G1 lane; 0 = off (measured slower: two batches pay the latency-bound stages twice)
+  Lane g1_lane;  // the G1 stream: sealed transcripts run their MSM batch, canonicalisation and digest here
   hipStream_t main_stream = nullptr;
   hipEvent_t fork_ev = nullptr;
   uint32_t next_lane = 0;
   bool lanes_enabled = true;
+  // main stream waits for the worker lanes (NOT for the G1 stream: a sealed proof keeps running there
+  // under the next proof's Fr phase; whoever touches its transcript waits on that transcript's own event)
   void join_lanes() {
     for (auto& l : lanes)
       if (l.dirty) {
         (void)hipStreamWaitEvent(main_stream, l.done, 0);
         l.dirty = false;
       }
-    if (g1_lane.dirty) {
-      (void)hipStreamWaitEvent(main_stream, g1_lane.done, 0);
-      g1_lane.dirty = false;
-    }
     // restart the round-robin: the same call sequence then lands on the same lanes every proof, so each
     // lane's pool sees the same sizes and stays warm (a shifting assignment kept missing -> hipMalloc stalls)
     next_lane = 0;
+  }
+  // `st` additionally waits for everything enqueued on the G1 stream so far
+  void wait_g1(hipStream_t st) {
+    if (g1_lane.dirty) (void)hipStreamWaitEvent(st, g1_lane.done, 0);
+  }
+  void join_all() {
+    join_lanes();
+    wait_g1(main_stream);
+    g1_lane.dirty = false;
   }
 
   int fail(int code, const std::string& msg) {

@@ -142,6 +142,7 @@ using namespace zk;
 
 // ------------------------------------------------------------------ transcript
 int zk_transcript::ensure(size_t add_fr, size_t add_g1) {
+  unseal();
   if (n_fr + add_fr > cap_fr || n_g1 + add_g1 > cap_g1) ctx->join_lanes();  // lanes may still be writing the old buffers
   if (n_fr + add_fr > cap_fr) {
     size_t want = n_fr + add_fr;
@@ -169,36 +170,54 @@ int zk_transcript::ensure(size_t add_fr, size_t add_g1) {
   return ZK_OK;
 }
 
+void zk_transcript::unseal() {
+  if (!sealed) return;
+  (void)hipStreamWaitEvent(ctx->main_stream, sealed_ev, 0);
+  sealed = false;
+  deferred_keep.clear();  // owned by worker-lane pools; lanes fork from the main stream, i.e. behind this wait
+}
+
 int zk_transcript::flush() {
+  unseal();
   ctx->join_lanes();
   ZK_TRY(msm_flush(ctx, &queue));
   if (n_g1 > n_g1_final && ctx->msm_mode == ZK_MSM_PIPPENGER) ZK_TRY(g1_canonicalise_dev(ctx, g1_d + n_g1_final, (uint32_t)(n_g1 - n_g1_final)));
   n_g1_final = n_g1;
-  deferred_keep.clear();  // the G1 lane has been joined: its batches no longer read these scalars
   return ZK_OK;
 }
 
-// Run the MSMs enqueued so far as one batch on the G1 lane.  Their scalar-prep kernels ran on worker
-// lanes, so the G1 stream first waits on every dirty lane's `done` event; the batch then overlaps the
-// Fr work of the layers still to come.  Scratch comes from the G1 lane's own pool; the prepared
-// scalars (owned by worker-lane pools) are only released at the final flush, after the G1 lane is joined.
-int zk_transcript::flush_early() {
+// The G1 phase of a proof (MSM batch -> canonical outputs -> digest) as one asynchronous unit on the G1
+// stream.  The scalar-prep kernels of the queued MSMs ran on worker lanes, so the G1 stream first waits on
+// the main stream and on every dirty lane; the main stream does not wait for the G1 stream, so the next
+// proof's Fr phase (worker lanes) runs under this proof's MSM tail.  Scratch comes from the G1 stream's own
+// pool; the prepared scalars (worker-lane pools) are held until unseal().
+int zk_transcript::seal(uint64_t* out8_d) {
   zk_ctx::Lane& g = ctx->g1_lane;
-  if (!g.stream || queue.jobs.empty() || ctx->stream != ctx->main_stream) return ZK_OK;
+  if (!g.stream || !ctx->lanes_enabled || ctx->lanes.empty() || ctx->stream != ctx->main_stream) {
+    ZK_TRY(flush());  // no G1 stream: same result, synchronously ordered on the main stream
+    return out8_d ? transcript_digest_dev(ctx, fr_d, n_fr, g1_d, n_g1, nullptr, out8_d) : ZK_OK;
+  }
+  unseal();
+  if (!sealed_ev && hipEventCreateWithFlags(&sealed_ev, hipEventDisableTiming) != hipSuccess) return ctx->fail(ZK_ERR_DEVICE, "hipEventCreate failed");
   (void)hipEventRecord(ctx->fork_ev, ctx->main_stream);
   (void)hipStreamWaitEvent(g.stream, ctx->fork_ev, 0);
   for (auto& l : ctx->lanes)
-    if (l.dirty) (void)hipStreamWaitEvent(g.stream, l.done, 0);
+    if (l.dirty) (void)hipStreamWaitEvent(g.stream, l.done, 0);  // stays dirty: the main stream has not joined it
   ctx->stream = g.stream;
   ctx->cur_pool = &g.pool;
-  int rc = msm_run_jobs(ctx, queue.jobs, queue.c);
-  if (rc == ZK_OK && n_g1 > n_g1_final) rc = g1_canonicalise_dev(ctx, g1_d + n_g1_final, (uint32_t)(n_g1 - n_g1_final));
+  int rc = ZK_OK;
+  if (!queue.jobs.empty()) rc = msm_run_jobs(ctx, queue.jobs, queue.c);
+  if (rc == ZK_OK && n_g1 > n_g1_final && ctx->msm_mode == ZK_MSM_PIPPENGER) rc = g1_canonicalise_dev(ctx, g1_d + n_g1_final, (uint32_t)(n_g1 - n_g1_final));
+  if (rc == ZK_OK && out8_d) rc = transcript_digest_dev(ctx, fr_d, n_fr, g1_d, n_g1, nullptr, out8_d);
+  (void)hipEventRecord(sealed_ev, g.stream);
   (void)hipEventRecord(g.done, g.stream);
   g.dirty = true;
+  sealed = true;
   ctx->stream = ctx->main_stream;
   ctx->cur_pool = &ctx->main_pool;
   n_g1_final = n_g1;
   queue.jobs.clear();
+  queue.c = 0;
   for (auto& b : queue.keep) deferred_keep.push_back(std::move(b));
   queue.keep.clear();
   return rc;
@@ -243,17 +262,8 @@ int fc_forward(zk_ctx* ctx, const zk_fc* fc, const Fr* x, uint32_t xn, Fr* z) {
 }
 
 // zkFC::prove, zkfc.cu:128-145
-static int fc_prove_lane(zk_ctx* ctx, zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint32_t zn, zk_gens* gens,
-                         const zk_fr* u_bs_h, const zk_fr* u_in_h, const zk_fr* u_out_h, zk_transcript* tr);
 int fc_prove(zk_ctx* ctx, zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint32_t zn, zk_gens* gens,
              const zk_fr* u_bs_h, const zk_fr* u_in_h, const zk_fr* u_out_h, zk_transcript* tr) {
-  ZK_TRY(fc_prove_lane(ctx, fc, x, xn, z, zn, gens, u_bs_h, u_in_h, u_out_h, tr));
-  // enough MSMs queued: start them now on the G1 lane, under the Fr work of the remaining layers
-  if (ctx->msm_early_jobs && ctx->lanes_enabled && !ctx->lanes.empty() && tr->queue.jobs.size() >= ctx->msm_early_jobs) return tr->flush_early();
-  return ZK_OK;
-}
-static int fc_prove_lane(zk_ctx* ctx, zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint32_t zn, zk_gens* gens,
-                         const zk_fr* u_bs_h, const zk_fr* u_in_h, const zk_fr* u_out_h, zk_transcript* tr) {
   const uint32_t n_gens = gens->n;
   if (xn % fc->in != 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions 1");
   const uint32_t batch = xn / fc->in;

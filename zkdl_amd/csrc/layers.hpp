@@ -63,9 +63,12 @@ struct zk_transcript {  // proof values in the order of SURVEY.md App. A.6, resi
   zk::MsmQueue queue;      // deferred MSMs whose results land in g1_d
   size_t n_g1_final = 0;   // G1 entries already flushed + canonicalised
   int ensure(size_t add_fr, size_t add_g1);
-  std::vector<zk::DBuf<zk::Fr>> deferred_keep;  // scalars of early batches, released at the final flush
-  int flush();             // run pending MSMs, canonicalise their outputs
-  int flush_early();       // run the MSMs queued so far on the G1 lane (no host wait, no main-stream wait)
+  std::vector<zk::DBuf<zk::Fr>> deferred_keep;  // prepared scalars of a sealed batch, released when it is unsealed
+  bool sealed = false;              // the G1 phase is (possibly still) running on the G1 stream
+  hipEvent_t sealed_ev = nullptr;   // recorded behind it
+  int flush();                      // run pending MSMs on the main stream, canonicalise their outputs
+  int seal(uint64_t* out8_d);       // the same plus the digest, on the G1 stream, with no main-stream wait
+  void unseal();                    // main stream waits for a sealed G1 phase; its scalars are released
 };
 
 namespace zk {

@@ -73,7 +73,9 @@ int gens_table(zk_ctx* ctx, zk_gens* g, uint32_t c, uint32_t W, const G1Table** 
   if (it != g->tables.end()) {
     // a wider table replaces a narrower one IN PLACE: queued jobs hold a pointer to this map node and
     // pick up the new (superset) arrays when they run; the old arrays go once the stream has drained
-    // (queued jobs have not been launched yet; launched ones are ordered before these frees)
+    // (queued jobs have not been launched yet; launched ones are ordered before these frees, including a
+    // sealed batch still running on the G1 stream)
+    ctx->wait_g1(ctx->stream);
     dev_free(ctx, it->second.pts);
     dev_free(ctx, it->second.inf);
     it->second = T;
