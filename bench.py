@@ -197,6 +197,7 @@ def main():
     ap.add_argument("--workload", default="mlp18m_b256", choices=sorted(WORKLOADS))
     ap.add_argument("--msm", default="pippenger", choices=["pippenger", "literal"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--msm-window", type=int, default=0, help="force the Pippenger window width (0 = library default)")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every proof on the main stream (no overlap of proof i's G1 phase with proof i+1's Fr phase)")
     ap.add_argument("--backend", default=os.environ.get("BENCH_BACKEND", "nccl"), help="nccl (= RCCL, default) | gloo (rehearsal on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses device 0")
@@ -222,28 +223,36 @@ def main():
     from zkdl_amd.capi import MSM_LITERAL, MSM_PIPPENGER, Zk
     zk = Zk(local_rank)
     zk.set_msm_mode(MSM_PIPPENGER if args.msm == "pippenger" else MSM_LITERAL)
+    if args.msm_window:
+        zk.set_msm_window(args.msm_window)
     dims, batch = WORKLOADS[args.workload]
     wl = Workload(zk, dims, batch, seed=rank)
 
     # The G1 phase of every proof (MSM batch, canonicalisation, digest) and the all-reduce of its digest are
     # ordered on the library's G1 stream; the Fr phase of the next proof runs beside them on the worker lanes.
     pipelined = not args.no_pipeline
-    stream_ptr = zk.lib.zk_ctx_g1_stream(zk.ctx) if pipelined else zk.lib.zk_ctx_stream(zk.ctx)
-    ext = torch.cuda.ExternalStream(stream_ptr, device=torch.device("cuda", local_rank))
-    agg = torch.zeros(8, dtype=torch.int64, device="cuda")
+    aggs = [torch.zeros(8, dtype=torch.int64, device="cuda") for _ in range(2)]
+    ext_streams = {}
     torch.cuda.synchronize()
+
+    def ext_stream(ptr):
+        if ptr not in ext_streams:
+            ext_streams[ptr] = torch.cuda.ExternalStream(ptr, device=torch.device("cuda", local_rank))
+        return ext_streams[ptr]
 
     def step(i):
         chal = wl.challenges(i)
         tr = wl.trs[i & 1] if pipelined else wl.tr
+        agg = aggs[i & 1]
         wl.prove(chal, tr)
         if pipelined:
             tr.seal(agg.data_ptr())
         else:
             tr.digest_dev(agg.data_ptr())
         if world > 1:
-            with torch.cuda.stream(ext):
+            with torch.cuda.stream(ext_stream(tr.stream() if pipelined else zk.lib.zk_ctx_stream(zk.ctx))):
                 dist.all_reduce(agg, op=dist.ReduceOp.SUM)      # RCCL over xGMI: 8 x uint64 lanes
+        return agg
 
     def barrier():
         zk.sync()
@@ -261,7 +270,7 @@ def main():
     gc.disable()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        agg = step(i)
     t_enq = time.perf_counter() - t0          # host time to enqueue K steps (no device wait inside)
     barrier()
     elapsed = time.perf_counter() - t0

@@ -54,7 +54,6 @@ int zk_ctx_sync(zk_ctx* ctx);
 const char* zk_last_error(const zk_ctx* ctx);     /* message of the last non-OK status */
 const char* zk_version(void);
 void* zk_ctx_stream(zk_ctx* ctx);                 /* the hipStream_t, for callers that interleave */
-void* zk_ctx_g1_stream(zk_ctx* ctx);              /* the hipStream_t sealed transcripts finish on (see zk_transcript_seal) */
 /* cudaMalloc / cudaFree / cudaMemcpy in FrTensor and G1Tensor ctors (fr-tensor.cu:92-120) */
 int zk_malloc(zk_ctx* ctx, size_t bytes, void** out_d);
 int zk_free(zk_ctx* ctx, void* ptr_d);
@@ -225,13 +224,16 @@ int zk_transcript_digest(zk_transcript* tr, zk_fr* out_h);
  * uint64 (exact for < 2^32 ranks), then carry-propagate and reduce mod r locally */
 int zk_transcript_digest_dev(zk_transcript* tr, uint64_t* out8_d);
 /* Finish the proof ASYNCHRONOUSLY: the deferred MSM batch, the canonicalisation of its outputs and (when
- * out8_d is not NULL) the digest_dev above run on the context's G1 stream (zk_ctx_g1_stream), behind the
- * Fr work already enqueued, and the main stream does NOT wait for them.  A caller proving a stream of
+ * out8_d is not NULL) the digest_dev above run on one of the context's G1 streams (zk_transcript_stream
+ * tells which), behind the Fr work already enqueued, and the main stream does NOT wait for them.  A caller proving a stream of
  * batches alternates two transcripts: the G1 phase of proof i then runs under the Fr phase of proof i+1.
  * Any later call on the SAME transcript (read, digest, counts, reset, flush, destroy), and zk_ctx_sync,
- * waits for the sealed phase first; work that consumes out8_d must be ordered on the G1 stream.
+ * waits for the sealed phase first; work that consumes out8_d must be ordered on zk_transcript_stream(tr).
  * Without worker lanes this degrades to flush + digest_dev on the main stream (same values). */
 int zk_transcript_seal(zk_transcript* tr, uint64_t* out8_d);
+/* the hipStream_t the last zk_transcript_seal of this transcript was enqueued on (the main stream if it ran
+ * synchronously or was never sealed) */
+void* zk_transcript_stream(zk_transcript* tr);
 
 #ifdef __cplusplus
 }

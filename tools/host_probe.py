@@ -26,10 +26,11 @@ for it in range(int(os.environ.get('ITERS','4'))):
             wl.relus[i].prove(wl.Z[i], wl.A[i], ch, wl.tr)
         rows.append((kind, i, (time.perf_counter() - a) * 1e3))
     t2 = time.perf_counter()
-    wl.tr.flush()
+    zk.sync()                      # Fr phase drained (worker lanes joined)
     t3 = time.perf_counter()
-    zk.sync()
+    wl.tr.flush()
+    zk.sync()                      # G1 phase drained
     t4 = time.perf_counter()
     worst = max(rows, key=lambda r: r[2])
-    print(f"iter {it}: worst call {worst[0]}{worst[1]} {worst[2]:.2f} ms; challenges {1e3*(t1-t0):.2f} ms, prove calls {1e3*(t2-t1):.2f} ms, flush enqueue {1e3*(t3-t2):.2f} ms, drain {1e3*(t4-t3):.2f} ms, total {1e3*(t4-t0):.2f}")
+    print(f"iter {it}: worst call {worst[0]}{worst[1]} {worst[2]:.2f} ms; challenges {1e3*(t1-t0):.2f} ms, prove calls {1e3*(t2-t1):.2f} ms, Fr drain {1e3*(t3-t2):.2f} ms (Fr phase {1e3*(t3-t1):.2f}), G1 phase {1e3*(t4-t3):.2f} ms, total {1e3*(t4-t0):.2f}")
 print(" ".join(f"{k}{i}:{ms:.2f}" for k, i, ms in rows))

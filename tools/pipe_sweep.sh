@@ -1,10 +1,11 @@
-run() { timeout -k 10 200 python bench.py --steps 16 --warmup 3 --no-cpu-baseline $2 > gpurun_out/sw.log 2>&1 || { tail -5 gpurun_out/sw.log; exit 1; }
+run() { timeout -k 10 120 python bench.py --steps 16 --warmup 3 --no-cpu-baseline $2 > gpurun_out/sw.log 2>&1 || { echo "$1 FAILED/timeout"; tail -3 gpurun_out/sw.log; return 0; }
 python3 -c "
 import json,sys
 d=json.loads(open('gpurun_out/sw.log').read().strip().split('\n')[-1])
-print(sys.argv[1], round(d['ms_per_step'],2), round(d['host_enqueue_ms_per_step'],2), d['aggregate_fr'][:18])
+k=d['kernels']
+print(sys.argv[1], round(d['ms_per_step'],2), round(d['host_enqueue_ms_per_step'],2), d['aggregate_fr'][:14], 'launches', sum(v['launches_per_step'] for v in k.values()))
 " "$1"; }
-run "pipelined" ""
-run "no-pipeline" "--no-pipeline"
-ZKDL_LANES=12 run "pipelined lanes=12" ""
-ZKDL_LANES=16 run "pipelined lanes=16" ""
+run "batched pipelined" ""
+run "batched nopipe" "--no-pipeline"
+cp gpurun_out/sw.log gpurun_out/bench_batched_nopipe.log
+ITERS=5 timeout -k 10 200 python tools/host_probe.py 2>&1 | grep "iter [1-4]" | cut -c1-220

@@ -22,7 +22,7 @@ ZK_OK, ZK_ERR_SHAPE, ZK_ERR_ALLOC, ZK_ERR_DEVICE, ZK_ERR_ARG, ZK_ERR_RANGE = ran
 MSM_LITERAL, MSM_PIPPENGER = 0, 1
 
 # every symbol include/zkdl_amd.h declares (checked by tests/test_capi_symbols.py)
-SYMBOLS = """zk_ctx_create zk_ctx_destroy zk_ctx_sync zk_last_error zk_version zk_ctx_stream zk_ctx_g1_stream zk_malloc zk_free
+SYMBOLS = """zk_ctx_create zk_ctx_destroy zk_ctx_sync zk_last_error zk_version zk_ctx_stream zk_malloc zk_free
 zk_memcpy_h2d zk_memcpy_d2h zk_memcpy_d2d zk_memset_zero zk_timer_start zk_timer_stop_ms zk_prof_enable zk_prof_reset
 zk_prof_read zk_rng_seed zk_random_vec zk_fr_random zk_fr_random_int zk_ceil_log2 zk_fr_add zk_fr_sub zk_fr_mul zk_fr_neg
 zk_fr_add_scalar zk_fr_sub_scalar zk_fr_mul_scalar zk_fr_mont zk_fr_unmont zk_fr_sum zk_fr_me zk_fr_partial_me_size
@@ -33,7 +33,7 @@ zk_set_msm_window zk_set_flag zk_gens_create zk_gens_destroy zk_gens_size zk_gen
 zk_fc_out zk_fc_com_size zk_fc_weights zk_fc_com zk_fc_load_input zk_fc_forward zk_fc_prove zk_relu_create
 zk_relu_destroy zk_relu_forward zk_relu_sign zk_relu_mag_bin zk_relu_rem_bin zk_relu_prove zk_transcript_create
 zk_transcript_destroy zk_transcript_reset zk_transcript_flush zk_transcript_counts zk_transcript_read zk_transcript_read_affine
-zk_transcript_digest zk_transcript_digest_dev zk_transcript_seal""".split()
+zk_transcript_digest zk_transcript_digest_dev zk_transcript_seal zk_transcript_stream""".split()
 
 
 class ZkError(RuntimeError):
@@ -516,6 +516,10 @@ class Transcript:
     def seal(self, out8_ptr=None):
         """Finish the proof on the G1 stream without making the main stream wait (zk_transcript_seal)."""
         self.zk._chk(self.zk.lib.zk_transcript_seal(self.h, _vp(out8_ptr) if out8_ptr else None))
+
+    def stream(self):
+        """hipStream_t (as int) the last seal() was enqueued on."""
+        return self.zk.lib.zk_transcript_stream(self.h)
 
     def close(self):
         if self.h:

@@ -14,9 +14,14 @@ static_assert(sizeof(zk_fr) == sizeof(Fr) && sizeof(zk_fp) == sizeof(Fp), "POD l
 static_assert(sizeof(zk_g1a) == sizeof(G1A) && sizeof(zk_g1j) == sizeof(G1J), "POD layout");
 
 // every entry point except the lane-parallel provers first joins the worker lanes
-#define CHECK_CTX(ctx)            \
-  if (!(ctx)) return ZK_ERR_ARG;  \
-  (ctx)->join_lanes()
+// every entry point except the prove calls first runs recorded-but-unexecuted layer work and joins the
+// worker lanes, so callers observe plain stream order
+#define CHECK_CTX(ctx)                                  \
+  if (!(ctx)) return ZK_ERR_ARG;                        \
+  do {                                                  \
+    int _src = (ctx)->settle();                         \
+    if (_src != ZK_OK) return _src;                     \
+  } while (0)
 #define CHECK_CTX_NOJOIN(ctx) \
   if (!(ctx)) return ZK_ERR_ARG
 #define CHECK_PTR(ctx, p)                                                                  \
@@ -58,7 +63,8 @@ void* zk_ctx::stage_put(const void* src, size_t bytes) {
     if (!mark(main_stream)) return nullptr;
     for (auto& l : lanes)
       if (!mark(l.stream)) return nullptr;
-    if (g1_lane.stream && !mark(g1_lane.stream)) return nullptr;
+    for (auto& g : g1_lanes)
+      if (!mark(g.stream)) return nullptr;
     stage_marked[seg] = e;
     seg = (seg + 1) % STAGE_SEGS;
     for (size_t q = 0; q < stage_marked[seg]; q++)
@@ -74,8 +80,20 @@ void* zk_ctx::stage_put(const void* src, size_t bytes) {
 
 void zk_ctx::prof_flush() {
   if (pending.empty()) return;
-  join_lanes();
+  join_all();
   (void)hipStreamSynchronize(main_stream);
+  // ZKDL_PROF_TRACE=<file>: additionally append one line per launch (name, stream index, start and duration
+  // in microseconds since profiling was enabled, algorithmic bytes) -- a timeline without an external profiler
+  FILE* trace = nullptr;
+  if (const char* path = getenv("ZKDL_PROF_TRACE")) trace = fopen(path, "a");
+  auto stream_index = [&](hipStream_t st) {
+    if (st == main_stream) return 0;
+    for (size_t i = 0; i < lanes.size(); i++)
+      if (lanes[i].stream == st) return (int)i + 1;
+    for (size_t i = 0; i < g1_lanes.size(); i++)
+      if (g1_lanes[i].stream == st) return 90 + (int)i;
+    return -1;
+  };
   for (auto& p : pending) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
@@ -84,10 +102,14 @@ void zk_ctx::prof_flush() {
       e.ms += ms;
       e.launches += 1;
       e.bytes += p.bytes;
+      float t0ms = 0;
+      if (trace && prof_base && hipEventElapsedTime(&t0ms, prof_base, p.a) == hipSuccess)
+        fprintf(trace, "%s,%d,%.2f,%.2f,%llu\n", p.name, stream_index(p.stream), t0ms * 1e3, ms * 1e3, (unsigned long long)p.bytes);
     }
     event_pool.push_back(p.a);
     event_pool.push_back(p.b);
   }
+  if (trace) fclose(trace);
   pending.clear();
 }
 
@@ -120,9 +142,24 @@ int zk_ctx_create(int device, zk_ctx** out) {
         ctx->lanes.clear();  // no lanes: everything stays on the main stream
         break;
       }
-    if (!ctx->lanes.empty() &&
-        (hipStreamCreateWithFlags(&ctx->g1_lane.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->g1_lane.done, hipEventDisableTiming) != hipSuccess))
-      ctx->g1_lane.stream = nullptr;
+    // G1 stream priority: the MSM batch is bulk work that should fill the gaps the latency-bound Fr chains
+    // leave, not delay them (ZKDL_G1_PRIO = -1 low, 0 normal (default; low priority with more than the default number of hardware queues stalled the pipeline), 1 high)
+    int g1_prio = 0;
+    if (const char* e = getenv("ZKDL_G1_PRIO")) g1_prio = atoi(e);
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    int prio = g1_prio < 0 ? least : g1_prio > 0 ? greatest : (least + greatest) / 2;
+    {
+      int ng = 1;
+      if (const char* e = getenv("ZKDL_G1_STREAMS")) ng = atoi(e);
+      ng = ng < 0 ? 0 : ng > 4 ? 4 : ng;
+      ctx->g1_lanes.resize((size_t)ng);
+      for (auto& g : ctx->g1_lanes)
+        if (hipStreamCreateWithPriority(&g.stream, hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&g.done, hipEventDisableTiming) != hipSuccess) {
+          ctx->g1_lanes.clear();  // sealing then degrades to the synchronous path
+          break;
+        }
+    }
   }
   ctx->stage_cap = 16u << 20;
   if (hipHostMalloc((void**)&ctx->stage, ctx->stage_cap, hipHostMallocDefault) != hipSuccess) {
@@ -142,9 +179,12 @@ int zk_ctx_destroy(zk_ctx* ctx) {
     if (l.stream) (void)hipStreamDestroy(l.stream);
     if (l.done) (void)hipEventDestroy(l.done);
   }
-  if (ctx->g1_lane.stream) (void)hipStreamDestroy(ctx->g1_lane.stream);
-  if (ctx->g1_lane.done) (void)hipEventDestroy(ctx->g1_lane.done);
+  for (auto& g : ctx->g1_lanes) {
+    if (g.stream) (void)hipStreamDestroy(g.stream);
+    if (g.done) (void)hipEventDestroy(g.done);
+  }
   (void)hipEventDestroy(ctx->fork_ev);
+  if (ctx->prof_base) (void)hipEventDestroy(ctx->prof_base);
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   (void)hipEventDestroy(ctx->t0);
   (void)hipEventDestroy(ctx->t1);
@@ -164,7 +204,6 @@ int zk_ctx_sync(zk_ctx* ctx) {
 }
 const char* zk_last_error(const zk_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
 void* zk_ctx_stream(zk_ctx* ctx) { return ctx ? (void*)ctx->main_stream : nullptr; }
-void* zk_ctx_g1_stream(zk_ctx* ctx) { return ctx ? (void*)(ctx->g1_lane.stream ? ctx->g1_lane.stream : ctx->main_stream) : nullptr; }
 
 int zk_malloc(zk_ctx* ctx, size_t bytes, void** out_d) {
   CHECK_CTX(ctx);
@@ -214,6 +253,10 @@ int zk_prof_enable(zk_ctx* ctx, int on) {
   CHECK_CTX(ctx);
   ctx->prof_flush();
   ctx->prof_on = on != 0;
+  if (ctx->prof_on) {
+    if (!ctx->prof_base && hipEventCreate(&ctx->prof_base) != hipSuccess) ctx->prof_base = nullptr;
+    if (ctx->prof_base) (void)hipEventRecord(ctx->prof_base, ctx->main_stream);
+  }
   return ZK_OK;
 }
 int zk_prof_reset(zk_ctx* ctx) {
@@ -246,7 +289,7 @@ int zk_rng_seed(zk_ctx* ctx, uint64_t seed) {
   return ZK_OK;
 }
 int zk_random_vec(zk_ctx* ctx, uint32_t len, zk_fr* out_h) {
-  CHECK_CTX(ctx);
+  CHECK_CTX_NOJOIN(ctx);  // host-only: no reason to make the main stream wait for the worker lanes
   if (len) CHECK_HOST(ctx, out_h);
   uint64_t draw = ctx->rng_draw++;
   for (uint32_t i = 0; i < len; i++) {
@@ -497,6 +540,7 @@ int zk_set_flag(zk_ctx* ctx, const char* name, int value) {
   CHECK_HOST(ctx, name);
   if (!strcmp(name, "relu_packed")) ctx->relu_packed = value != 0;
   else if (!strcmp(name, "lanes")) ctx->lanes_enabled = value != 0;
+  else if (!strcmp(name, "batch_layers")) ctx->batch_layers = value != 0;
   else return ctx->fail(ZK_ERR_ARG, std::string("unknown flag: ") + name);
   return ZK_OK;
 }
@@ -513,7 +557,10 @@ int zk_gens_create(zk_ctx* ctx, const zk_g1j* gens, uint32_t n, zk_gens** out) {
 }
 int zk_gens_destroy(zk_gens* g) {
   if (!g) return ZK_ERR_ARG;
-  if (g->ctx) g->ctx->join_all();  // a sealed proof may still be reading the window tables on the G1 stream
+  if (g->ctx) {
+    (void)g->ctx->settle();
+    g->ctx->join_all();  // a sealed proof may still be reading the window tables on the G1 stream
+  }
   gens_destroy(g);
   return ZK_OK;
 }
@@ -595,7 +642,10 @@ int zk_fc_from_float(zk_ctx* ctx, uint32_t in, uint32_t out, const float* w, zk_
 }
 int zk_fc_destroy(zk_fc* fc) {
   if (!fc) return ZK_ERR_ARG;
-  if (fc->ctx) fc->ctx->join_all();
+  if (fc->ctx) {
+    (void)fc->ctx->settle();
+    fc->ctx->join_all();
+  }
   if (fc->ctx) dev_free(fc->ctx, fc->weights);
   gens_destroy(fc->com);
   delete fc;
@@ -630,12 +680,13 @@ int zk_relu_create(zk_ctx* ctx, zk_relu** out) {
   CHECK_CTX(ctx);
   CHECK_HOST(ctx, out);
   *out = new zk_relu();
+  (*out)->serial = ctx->layer_serial++;
   (*out)->ctx = ctx;
   return ZK_OK;
 }
 int zk_relu_destroy(zk_relu* relu) {
   if (!relu) return ZK_ERR_ARG;
-  if (relu->ctx) relu->ctx->join_lanes();
+  if (relu->ctx) (void)relu->ctx->settle();  // recorded layer work may still reference the aux tensors
   relu->free_all();
   delete relu;
   return ZK_OK;
@@ -677,8 +728,9 @@ int zk_transcript_destroy(zk_transcript* tr) {
 }
 int zk_transcript_reset(zk_transcript* tr) {
   if (!tr) return ZK_ERR_ARG;
-  tr->ctx->join_lanes();
-  int rc = tr->flush();  // pending MSMs own scratch that must be released in stream order
+  int rc = ZK_OK;
+  tr->unseal();                                // a sealed G1 phase may still be reading the buffers
+  if (!tr->queue.jobs.empty()) rc = tr->flush();  // pending MSMs own scratch that must be released in stream order
   tr->n_fr = tr->n_g1 = tr->n_g1_final = 0;
   return rc;
 }
@@ -692,6 +744,7 @@ int zk_transcript_seal(zk_transcript* tr, uint64_t* out8_d) {
   if (out8_d && (((uintptr_t)out8_d) & 7u)) return tr->ctx->fail(ZK_ERR_ARG, "misaligned pointer: out8_d");
   return tr->seal(out8_d);
 }
+void* zk_transcript_stream(zk_transcript* tr) { return tr ? (void*)(tr->sealed_stream ? tr->sealed_stream : tr->ctx->main_stream) : nullptr; }
 int zk_transcript_counts(zk_transcript* tr, size_t* n_fr, size_t* n_g1) {
   if (!tr) return ZK_ERR_ARG;
   tr->ctx->join_lanes();

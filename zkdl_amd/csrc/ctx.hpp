@@ -27,6 +27,10 @@ struct zk_prof_entry {
   uint64_t bytes = 0;
 };
 
+namespace zk {
+struct Recorder;
+}
+
 struct zk_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -45,8 +49,10 @@ struct zk_ctx {
     const char* name;
     uint64_t bytes;
     hipEvent_t a, b;
+    hipStream_t stream;
   };
   std::vector<Pending> pending;
+  hipEvent_t prof_base = nullptr;  // recorded when profiling is switched on: origin of the ZKDL_PROF_TRACE timeline
   std::vector<hipEvent_t> event_pool;
   std::map<std::string, zk_prof_entry> prof;
   // pinned staging ring for small host->device uploads (challenge vectors, broadcast scalars):
@@ -88,6 +94,7 @@ struct zk_ctx {
       if (c >= bytes) return c;
     return p;
   }
+  bool rec_defer_free(void* p);
   void* pool_alloc(size_t bytes) {
     size_t cls = pool_class(bytes);
     auto& fl = cur_pool->free_lists[cls];
@@ -110,6 +117,7 @@ struct zk_ctx {
   }
   void pool_release(void* p) {
     if (!p) return;
+    if (rec_defer_free(p)) return;  // recording: the block stays live until the recorded launches have run
     auto it = blocks.find(p);
     if (it == blocks.end()) return;  // not ours (never happens for library-made pointers)
     if (it->second.idle) {  // releasing twice would hand one block to two owners: refuse and remember
@@ -125,7 +133,7 @@ struct zk_ctx {
     blocks.clear();
     main_pool.free_lists.clear();
     for (auto& l : lanes) l.pool.free_lists.clear();
-    g1_lane.pool.free_lists.clear();
+    for (auto& g : g1_lanes) g.pool.free_lists.clear();
   }
 
   // ---- lanes: worker streams for independent per-layer proofs (zk_fc_prove / zk_relu_prove).
@@ -140,10 +148,13 @@ struct zk_ctx {
     bool dirty = false;
   };
   std::vector<Lane> lanes;
-  Lane g1_lane;  // the G1 stream: sealed transcripts run their MSM batch, canonicalisation and digest here
+  // G1 streams: a sealed transcript runs its MSM batch, canonicalisation and digest on one of these
+  // (round-robin), so the latency-bound tail of one proof's G1 phase overlaps the next one's accumulation
+  std::vector<Lane> g1_lanes;
+  uint32_t next_g1 = 0;
   hipStream_t main_stream = nullptr;
   hipEvent_t fork_ev = nullptr;
-  uint32_t next_lane = 0;
+  uint32_t layer_serial = 0;  // next zk_fc / zk_relu serial number (their lane hint)
   bool lanes_enabled = true;
   // main stream waits for the worker lanes (NOT for the G1 stream: a sealed proof keeps running there
   // under the next proof's Fr phase; whoever touches its transcript waits on that transcript's own event)
@@ -153,18 +164,16 @@ struct zk_ctx {
         (void)hipStreamWaitEvent(main_stream, l.done, 0);
         l.dirty = false;
       }
-    // restart the round-robin: the same call sequence then lands on the same lanes every proof, so each
-    // lane's pool sees the same sizes and stays warm (a shifting assignment kept missing -> hipMalloc stalls)
-    next_lane = 0;
   }
-  // `st` additionally waits for everything enqueued on the G1 stream so far
+  // `st` additionally waits for everything enqueued on the G1 streams so far
   void wait_g1(hipStream_t st) {
-    if (g1_lane.dirty) (void)hipStreamWaitEvent(st, g1_lane.done, 0);
+    for (auto& g : g1_lanes)
+      if (g.dirty) (void)hipStreamWaitEvent(st, g.done, 0);
   }
   void join_all() {
     join_lanes();
     wait_g1(main_stream);
-    g1_lane.dirty = false;
+    for (auto& g : g1_lanes) g.dirty = false;
   }
 
   int fail(int code, const std::string& msg) {
@@ -182,6 +191,16 @@ struct zk_ctx {
     return e;
   }
   void prof_flush();
+
+  // ---- deferred, horizontally batched execution of the layers' Fr work (launch.hpp / recorder)
+  // While `rec` is set, every launch made through ZK_LAUNCH is RECORDED into the current chain instead
+  // of being enqueued, temporaries are kept alive, and small host uploads go into the recorder's blob.
+  // `pending` lists the recorders that hold unexecuted chains; settle() runs them (then joins the lanes)
+  // so that every other entry point observes plain stream order.
+  zk::Recorder* rec = nullptr;
+  std::vector<zk::Recorder*> pending_recs;
+  bool batch_layers = true;
+  int settle();
 };
 
 namespace zk {
@@ -215,18 +234,21 @@ struct ProfScope {
   ~ProfScope() {
     if (a && b) {
       (void)hipEventRecord(b, ctx->stream);
-      ctx->pending.push_back({name, bytes, a, b});
+      ctx->pending.push_back({name, bytes, a, b, ctx->stream});
     }
   }
 };
 
-// RAII: run the enclosed work on the next worker lane (no-op when lanes are disabled or unavailable).
+// RAII: run the enclosed work on a worker lane (no-op when lanes are disabled or unavailable).  `hint`
+// is the layer object's serial number: a layer always proves on the same lane, so that lane's pool sees
+// the same allocation sizes every proof and stays warm, and successive proofs of one layer simply queue
+// behind each other in stream order.
 struct LaneScope {
   zk_ctx* ctx;
   zk_ctx::Lane* lane = nullptr;
-  explicit LaneScope(zk_ctx* c) : ctx(c) {
-    if (!c->lanes_enabled || c->lanes.empty() || c->stream != c->main_stream) return;
-    lane = &c->lanes[c->next_lane++ % c->lanes.size()];
+  LaneScope(zk_ctx* c, uint32_t hint) : ctx(c) {
+    if (hint == ~0u || !c->lanes_enabled || c->lanes.empty() || c->stream != c->main_stream) return;
+    lane = &c->lanes[hint % c->lanes.size()];
     (void)hipEventRecord(c->fork_ev, c->main_stream);
     (void)hipStreamWaitEvent(lane->stream, c->fork_ev, 0);
     c->stream = lane->stream;
@@ -241,16 +263,9 @@ struct LaneScope {
   }
 };
 
-// launch on the context's stream; `bytes` = algorithmic HBM bytes of this launch
-#define ZK_LAUNCH(ctx, name, bytes, kernel, grid, block, shmem, ...)                                     \
-  do {                                                                                                   \
-    {                                                                                                    \
-      zk::ProfScope _ps((ctx), (name), (uint64_t)(bytes));                                               \
-      hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);                        \
-    }                                                                                                    \
-    hipError_t _le = hipGetLastError();                                                                  \
-    if (_le != hipSuccess) return (ctx)->fail(ZK_ERR_DEVICE, std::string("launch of ") + (name) + " failed: " + hipGetErrorString(_le)); \
-  } while (0)
+}  // namespace zk
+#include "launch.hpp"
+namespace zk {
 
 // Persistent device buffers and temporaries both come from the context's caching allocator.
 inline hipError_t dev_alloc(zk_ctx* ctx, void** p, size_t bytes) {
@@ -267,28 +282,35 @@ struct DBuf {
   zk_ctx* ctx = nullptr;
   T* p = nullptr;
   size_t n = 0;
+  bool borrowed = false;  // points into memory owned by someone else (the recorder's blob)
   DBuf() = default;
   DBuf(zk_ctx* c, size_t count) { alloc(c, count); }
   DBuf(const DBuf&) = delete;
   DBuf& operator=(const DBuf&) = delete;
-  DBuf(DBuf&& o) noexcept : ctx(o.ctx), p(o.p), n(o.n) { o.p = nullptr; }
+  DBuf(DBuf&& o) noexcept : ctx(o.ctx), p(o.p), n(o.n), borrowed(o.borrowed) { o.p = nullptr; }
   DBuf& operator=(DBuf&& o) noexcept {
     release();
-    ctx = o.ctx; p = o.p; n = o.n;
+    ctx = o.ctx; p = o.p; n = o.n; borrowed = o.borrowed;
     o.p = nullptr;
     return *this;
+  }
+  void borrow(zk_ctx* c, T* ptr, size_t count) {
+    release();
+    ctx = c; p = ptr; n = count; borrowed = true;
   }
   bool alloc(zk_ctx* c, size_t count) {
     release();
     ctx = c;
     n = count;
+    borrowed = false;
     size_t bytes = (count ? count : 1) * sizeof(T);
     p = static_cast<T*>(c->pool_alloc(bytes));
     return p != nullptr;
   }
   void release() {
-    if (p) ctx->pool_release(p);
+    if (p && !borrowed) ctx->pool_release(p);
     p = nullptr;
+    borrowed = false;
   }
   ~DBuf() { release(); }
   T* get() const { return p; }
@@ -368,6 +390,12 @@ int g1_me_dev(zk_ctx* ctx, const G1J* t, uint32_t n, const Fr* u_d, uint32_t k, 
 int g1_to_affine_dev(zk_ctx* ctx, const G1J* a, uint32_t n, G1A* out, uint8_t* inf);
 // upload a host challenge vector (k may be 0)
 inline int upload_fr(zk_ctx* ctx, DBuf<Fr>& buf, const zk_fr* h, uint32_t k) {
+  if (ctx->rec && k) {  // recording: the vector travels in the recorder's blob, uploaded once per batch
+    void* d = rec_blob_put(ctx, h, (size_t)k * sizeof(Fr));
+    if (!d) return ctx->fail(ZK_ERR_ALLOC, "recorder blob exhausted");
+    buf.borrow(ctx, static_cast<Fr*>(d), k);
+    return ZK_OK;
+  }
   if (!buf.alloc(ctx, k ? k : 1)) return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: challenges");
   if (k) {
     void* st = ctx->stage_put(h, (size_t)k * sizeof(Fr));

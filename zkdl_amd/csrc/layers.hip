@@ -143,7 +143,10 @@ using namespace zk;
 // ------------------------------------------------------------------ transcript
 int zk_transcript::ensure(size_t add_fr, size_t add_g1) {
   unseal();
-  if (n_fr + add_fr > cap_fr || n_g1 + add_g1 > cap_g1) ctx->join_lanes();  // lanes may still be writing the old buffers
+  if (n_fr + add_fr > cap_fr || n_g1 + add_g1 > cap_g1) {
+    ZK_TRY(rec_execute(ctx, &rec));  // recorded chains hold pointers into the old buffers
+    ctx->join_lanes();               // lanes may still be writing them
+  }
   if (n_fr + add_fr > cap_fr) {
     size_t want = n_fr + add_fr;
     (void)want;
@@ -179,6 +182,7 @@ void zk_transcript::unseal() {
 
 int zk_transcript::flush() {
   unseal();
+  ZK_TRY(rec_execute(ctx, &rec));  // the layers' Fr work, zipped across layers (launch.hpp)
   ctx->join_lanes();
   ZK_TRY(msm_flush(ctx, &queue));
   if (n_g1 > n_g1_final && ctx->msm_mode == ZK_MSM_PIPPENGER) ZK_TRY(g1_canonicalise_dev(ctx, g1_d + n_g1_final, (uint32_t)(n_g1 - n_g1_final)));
@@ -192,12 +196,15 @@ int zk_transcript::flush() {
 // proof's Fr phase (worker lanes) runs under this proof's MSM tail.  Scratch comes from the G1 stream's own
 // pool; the prepared scalars (worker-lane pools) are held until unseal().
 int zk_transcript::seal(uint64_t* out8_d) {
-  zk_ctx::Lane& g = ctx->g1_lane;
-  if (!g.stream || !ctx->lanes_enabled || ctx->lanes.empty() || ctx->stream != ctx->main_stream) {
+  if (ctx->g1_lanes.empty() || !ctx->lanes_enabled || ctx->stream != ctx->main_stream) {
+    sealed_stream = nullptr;
     ZK_TRY(flush());  // no G1 stream: same result, synchronously ordered on the main stream
     return out8_d ? transcript_digest_dev(ctx, fr_d, n_fr, g1_d, n_g1, nullptr, out8_d) : ZK_OK;
   }
   unseal();
+  ZK_TRY(rec_execute(ctx, &rec));  // Fr phase on the main stream; the G1 stream waits for it below
+  zk_ctx::Lane& g = ctx->g1_lanes[ctx->next_g1++ % ctx->g1_lanes.size()];
+  sealed_stream = g.stream;
   if (!sealed_ev && hipEventCreateWithFlags(&sealed_ev, hipEventDisableTiming) != hipSuccess) return ctx->fail(ZK_ERR_DEVICE, "hipEventCreate failed");
   (void)hipEventRecord(ctx->fork_ev, ctx->main_stream);
   (void)hipStreamWaitEvent(g.stream, ctx->fork_ev, 0);
@@ -233,6 +240,7 @@ int fc_create(zk_ctx* ctx, uint32_t in, uint32_t out, const Fr* weights_d, zk_ge
   if (wn > 0xffffffffull || wn % n_gens != 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");  // commitment.cu:31 via zkfc.cu:102
   zk_fc* fc = new zk_fc();
   fc->ctx = ctx;
+  fc->serial = ctx->layer_serial++;
   fc->in = in;
   fc->out = out;
   fc->m = (uint32_t)(wn / n_gens);
@@ -280,7 +288,9 @@ int fc_prove(zk_ctx* ctx, zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint
   G1J* const g1_slot = tr->g1_d + tr->n_g1;
   tr->n_fr += add_fr;
   tr->n_g1 += add_g1;
-  LaneScope lane(ctx);  // declared before every temporary: they are released while the lane is current
+  RecScope recording(ctx, &tr->rec);  // batching on: this call only records its launches (one chain)
+  if (recording.rc != ZK_OK) return recording.rc;
+  LaneScope lane(ctx, recording.on ? ~0u : fc->serial);  // declared before every temporary: they are released while the lane is current
 
   // all challenges of this layer in one device array: [u_out | u_in | u_bs]  (so u_out||u_in is contiguous)
   std::vector<zk_fr> ch(k_out + k_in + k_bs + 1);
@@ -349,7 +359,9 @@ int relu_prove(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const Fr* z, uint3
   ZK_TRY(tr->ensure(add_fr, 0));
   Fr* out = tr->fr_d + tr->n_fr;
   tr->n_fr += add_fr;
-  LaneScope lane(ctx);  // declared before every temporary
+  RecScope recording(ctx, &tr->rec);
+  if (recording.rc != ZK_OK) return recording.rc;
+  LaneScope lane(ctx, recording.on ? ~0u : relu->serial);  // declared before every temporary
 
   const uint32_t lens[7] = {k + 5, k + 5, k + 4, k + 4, k, k, k};
   const zk_fr* hs[7] = {u_z_h, v_z_h, u_r_h, v_r_h, u_rec_h, u_hp_h, v_hp_h};

@@ -36,11 +36,12 @@ struct zk_fc {  // zkFC, zkfc.cuh:16-33: padded weights (Montgomery, [in][out]) 
   uint32_t in = 0, out = 0, m = 0, n_gens = 0;
   zk::Fr* weights = nullptr;
   zk_gens* com = nullptr;  // the m commitment points, wrapped so com(u) can run as a table MSM
+  uint32_t serial = 0;     // lane hint
 };
 
 struct zk_relu {  // zkReLU, zkrelu.cuh:10-20: aux tensors of the last forward pass
   zk_ctx* ctx = nullptr;
-  uint32_t n = 0, cap = 0;
+  uint32_t n = 0, cap = 0, serial = 0;
   zk::Fr *sign = nullptr, *mag_bin = nullptr, *rem_bin = nullptr;
   uint32_t* mag_packed = nullptr;  // the same bits, 32 per element
   uint16_t* rem_packed = nullptr;  // 15 remainder bits + sign bit
@@ -61,11 +62,13 @@ struct zk_transcript {  // proof values in the order of SURVEY.md App. A.6, resi
   zk::G1J* g1_d = nullptr;
   size_t n_fr = 0, n_g1 = 0, cap_fr = 0, cap_g1 = 0;
   zk::MsmQueue queue;      // deferred MSMs whose results land in g1_d
+  zk::Recorder rec;        // recorded (not yet executed) Fr work of the prove calls since the last flush
   size_t n_g1_final = 0;   // G1 entries already flushed + canonicalised
   int ensure(size_t add_fr, size_t add_g1);
   std::vector<zk::DBuf<zk::Fr>> deferred_keep;  // prepared scalars of a sealed batch, released when it is unsealed
   bool sealed = false;              // the G1 phase is (possibly still) running on the G1 stream
   hipEvent_t sealed_ev = nullptr;   // recorded behind it
+  hipStream_t sealed_stream = nullptr;  // where the last seal ran (nullptr: main stream)
   int flush();                      // run pending MSMs on the main stream, canonicalise their outputs
   int seal(uint64_t* out8_d);       // the same plus the digest, on the G1 stream, with no main-stream wait
   void unseal();                    // main stream waits for a sealed G1 phase; its scalars are released

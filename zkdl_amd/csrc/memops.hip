@@ -9,14 +9,14 @@
 
 namespace zk {
 
-__global__ void __launch_bounds__(256) k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+__device__ __forceinline__ void k_copy16(uint32_t zk_nblk, const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)zk_nblk * blockDim.x) dst[i] = src[i];
 }
-__global__ void __launch_bounds__(256) k_copy4(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+__device__ __forceinline__ void k_copy4(uint32_t zk_nblk, const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)zk_nblk * blockDim.x) dst[i] = src[i];
 }
-__global__ void __launch_bounds__(256) k_zero4(uint32_t* __restrict__ dst, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = 0u;
+__device__ __forceinline__ void k_zero4(uint32_t zk_nblk, uint32_t* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)zk_nblk * blockDim.x) dst[i] = 0u;
 }
 
 // src may be device memory or pinned (device-visible) host memory; sizes are multiples of 4 bytes
@@ -25,10 +25,10 @@ int dev_copy(zk_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (bytes & 3u) return ctx->fail(ZK_ERR_ARG, "dev_copy: size must be a multiple of 4 bytes");
   if ((((uintptr_t)dst | (uintptr_t)src | bytes) & 15u) == 0) {
     size_t n = bytes / 16;
-    ZK_LAUNCH(ctx, "copy", 2ull * bytes, k_copy16, dim3(stream_grid(n)), dim3(256), 0, (const uint4*)src, (uint4*)dst, n);
+    ZK_LAUNCHB(ctx, "copy", 2ull * bytes, 256, k_copy16, dim3(stream_grid(n)), 0, (const uint4*)src, (uint4*)dst, n);
   } else {
     size_t n = bytes / 4;
-    ZK_LAUNCH(ctx, "copy", 2ull * bytes, k_copy4, dim3(stream_grid(n)), dim3(256), 0, (const uint32_t*)src, (uint32_t*)dst, n);
+    ZK_LAUNCHB(ctx, "copy", 2ull * bytes, 256, k_copy4, dim3(stream_grid(n)), 0, (const uint32_t*)src, (uint32_t*)dst, n);
   }
   return ZK_OK;
 }
@@ -36,7 +36,7 @@ int dev_zero(zk_ctx* ctx, void* dst, size_t bytes) {
   if (bytes == 0) return ZK_OK;
   if (bytes & 3u) return ctx->fail(ZK_ERR_ARG, "dev_zero: size must be a multiple of 4 bytes");
   size_t n = bytes / 4;
-  ZK_LAUNCH(ctx, "copy", bytes, k_zero4, dim3(stream_grid(n)), dim3(256), 0, (uint32_t*)dst, n);
+  ZK_LAUNCHB(ctx, "copy", bytes, 256, k_zero4, dim3(stream_grid(n)), 0, (uint32_t*)dst, n);
   return ZK_OK;
 }
 // blocking host <-> device transfers: drain the stream first, then a synchronous copy

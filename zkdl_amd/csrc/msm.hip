@@ -89,9 +89,9 @@ int gens_table(zk_ctx* ctx, zk_gens* g, uint32_t c, uint32_t W, const G1Table** 
 
 // ------------------------------------------------------------------ scalar preparation
 // mag = min(s, r - s) with the sign in bit 255 (mag < 2^254); *maxbits = max bit length of mag.
-__global__ void __launch_bounds__(256) k_scalar_prep(const Fr* __restrict__ s, Fr* __restrict__ out, uint64_t total, int do_unmont, uint32_t* __restrict__ maxbits) {
+__device__ __forceinline__ void k_scalar_prep(uint32_t zk_nblk, const Fr* __restrict__ s, Fr* __restrict__ out, uint64_t total, int do_unmont, uint32_t* __restrict__ maxbits) {
   uint32_t mx = 0;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)zk_nblk * blockDim.x) {
     Fr v = s[i];
     if (do_unmont) v = fr_unmont(v);
     Fr nv = fr_neg(v);         // r - v (0 for v == 0)
@@ -435,7 +435,7 @@ int msm_enqueue(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_
   if (!mags.alloc(ctx, total)) return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: MSM scalars");
   ZK_ALLOC(ctx, maxbits, uint32_t, 1);
   ZK_TRY(dev_zero(ctx, maxbits.get(), 4));
-  ZK_LAUNCH(ctx, "msm_scalar_prep", 64ull * total, k_scalar_prep, dim3(stream_grid(total)), dim3(256), 0, scalars, mags.get(), total, do_unmont ? 1 : 0, maxbits.get());
+  ZK_LAUNCHB(ctx, "msm_scalar_prep", 64ull * total, 256, k_scalar_prep, dim3(stream_grid(total)), 0, scalars, mags.get(), total, do_unmont ? 1 : 0, maxbits.get());
   uint32_t bits = 254;
   if (probe_bits) {  // setup-time paths only (commit): one host round trip buys 10x fewer windows
     ZK_TRY(dev_to_host(ctx, &bits, maxbits.get(), 4));
@@ -478,7 +478,7 @@ int commit_pippenger_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, uint32_t tn, G1J*
 
 // ------------------------------------------------------------------ flattened opening
 // C[(2^r - 1) + l] = prod_{t<r} (bit_t(l) ? 1 - u_t : u_t)   (Montgomery form), r = 0..k
-__global__ void __launch_bounds__(256) k_mo_coef(const Fr* __restrict__ u, uint32_t k, Fr* __restrict__ C) {
+__device__ __forceinline__ void k_mo_coef(uint32_t zk_nblk, const Fr* __restrict__ u, uint32_t k, Fr* __restrict__ C) {
   uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t total = (2u << k) - 1u;
   if (idx >= total) return;
@@ -493,9 +493,9 @@ __global__ void __launch_bounds__(256) k_mo_coef(const Fr* __restrict__ u, uint3
 }
 // scal[(3r + e)*n + i] for rounds r < k, e in {T, T0, T1}; scal[3k*n + i] = unmont(C_k[i]).
 // S holds the folded scalar tensors back to back: S_r at offset 2n - (2n >> r).
-__global__ void __launch_bounds__(256) k_mo_scalars(const Fr* __restrict__ C, const Fr* __restrict__ S, uint32_t n, uint32_t k, Fr* __restrict__ scal) {
+__device__ __forceinline__ void k_mo_scalars(uint32_t zk_nblk, const Fr* __restrict__ C, const Fr* __restrict__ S, uint32_t n, uint32_t k, Fr* __restrict__ scal) {
   uint64_t total = (uint64_t)(k + 1) * n;
-  for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)gridDim.x * blockDim.x) {
+  for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)zk_nblk * blockDim.x) {
     uint32_t r = (uint32_t)(g / n), i = (uint32_t)(g - (uint64_t)r * n);
     if (r == k) {
       scal[(uint64_t)3 * k * n + i] = fr_unmont(C[(1u << k) - 1u + i]);
@@ -526,10 +526,10 @@ int me_open_flat_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32
   ZK_TRY(dev_copy(ctx, ret_d, S.get() + (2ull * n - 2), sizeof(Fr)));  // t(0) = S_k[0]
   uint32_t ncoef = (2u << k) - 1u;
   ZK_ALLOC(ctx, C, Fr, ncoef);
-  ZK_LAUNCH(ctx, "me_open_scalars", 32ull * ncoef, k_mo_coef, dim3((ncoef + 255) / 256), dim3(256), 0, u_d, k, C.get());
+  ZK_LAUNCHB(ctx, "me_open_scalars", 32ull * ncoef, 256, k_mo_coef, dim3((ncoef + 255) / 256), 0, u_d, k, C.get());
   uint32_t q = 3 * k + 1;
   ZK_ALLOC(ctx, scal, Fr, (size_t)q * n);
-  ZK_LAUNCH(ctx, "me_open_scalars", 32ull * q * n, k_mo_scalars, dim3(stream_grid((uint64_t)(k + 1) * n)), dim3(256), 0, (const Fr*)C.get(), (const Fr*)S.get(), n, k,
+  ZK_LAUNCHB(ctx, "me_open_scalars", 32ull * q * n, 256, k_mo_scalars, dim3(stream_grid((uint64_t)(k + 1) * n)), 0, (const Fr*)C.get(), (const Fr*)S.get(), n, k,
             scal.get());
   if (queue) return msm_enqueue(ctx, g, scal.get(), q, /*do_unmont=*/false, /*probe_bits=*/false, proof_d, queue);
   return msm_batch_dev(ctx, g, scal.get(), q, /*do_unmont=*/false, /*probe_bits=*/false, proof_d);
@@ -537,7 +537,7 @@ int me_open_flat_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32
 
 // com(u): sum_i eq(unmont u, i) * P_i over the (precomputed) commitment points -- the MSM form of
 // G1TensorJacobian::operator()(u) (g1-tensor.cu:463-491)
-__global__ void __launch_bounds__(256) k_eq_scalars(const Fr* __restrict__ u, uint32_t k, uint32_t m, Fr* __restrict__ out) {
+__device__ __forceinline__ void k_eq_scalars(uint32_t zk_nblk, const Fr* __restrict__ u, uint32_t k, uint32_t m, Fr* __restrict__ out) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= m) return;
   Fr one = fr_one(), acc = one;
@@ -552,7 +552,7 @@ int g1_me_msm_dev(zk_ctx* ctx, zk_gens* pts, const Fr* u_d, uint32_t k, G1J* dst
   if (m == 0 || k > 31 || m > (1u << k)) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   if (k > 0 && m <= (1u << (k - 1))) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   ZK_ALLOC(ctx, scal, Fr, m);
-  ZK_LAUNCH(ctx, "me_open_scalars", 32ull * m, k_eq_scalars, dim3((m + 255) / 256), dim3(256), 0, u_d, k, m, scal.get());
+  ZK_LAUNCHB(ctx, "me_open_scalars", 32ull * m, 256, k_eq_scalars, dim3((m + 255) / 256), 0, u_d, k, m, scal.get());
   if (queue) return msm_enqueue(ctx, pts, scal.get(), 1, /*do_unmont=*/false, /*probe_bits=*/false, dst_d, queue);
   return msm_batch_dev(ctx, pts, scal.get(), 1, /*do_unmont=*/false, /*probe_bits=*/false, dst_d);
 }

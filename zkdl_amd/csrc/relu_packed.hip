@@ -65,11 +65,11 @@ static PackedLayout packed_layout(uint32_t nb) {
 }
 
 // u = weight challenges, v = fold challenges (k each).  tab: PackedLayout; AH/BH: two-level Ehi tables.
-__global__ void __launch_bounds__(256) k_binp_prep(const Fr* __restrict__ u, const Fr* __restrict__ v, uint32_t k, PackedLayout L, uint32_t ch, Fr* __restrict__ tab,
+__device__ __forceinline__ void k_binp_prep(uint32_t zk_nblk, const Fr* __restrict__ u, const Fr* __restrict__ v, uint32_t k, PackedLayout L, uint32_t ch, Fr* __restrict__ tab,
                                                     Fr* __restrict__ AH, Fr* __restrict__ BH) {
   const uint32_t nAH = 1u << ch, nBH = 1u << (k - L.lognb - ch);
   const uint32_t total = L.total + nAH + nBH;
-  for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+  for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += zk_nblk * blockDim.x) {
     if (idx < L.off_t1) {  // Elo_0[i'] = eq(u[1..lognb), i')
       tab[idx] = idx < L.P0 ? eq_prod(u + 1, L.lognb - 1, idx) : fr_zero();
     } else if (idx < L.off_t2) {  // TS1[i'][q][nibble] = eq(u[2..lognb), i') * coef_q(a0, a1)
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256) k_binp_prep(const Fr* __restrict__ u, con
 
 // Rounds 0..2 of binary_sumcheck from packed bits.  partial[blk*7 + {0: c2 of round 0; 1..3: round 1; 4..6: round 2}]
 template <int NB, class WordT>
-__global__ void __launch_bounds__(512) k_binp_rounds(const WordT* __restrict__ packed, uint32_t n, PackedLayout L, const Fr* __restrict__ tab_g, const Fr* __restrict__ AH,
+__device__ __forceinline__ void k_binp_rounds(uint32_t zk_nblk, const WordT* __restrict__ packed, uint32_t n, PackedLayout L, const Fr* __restrict__ tab_g, const Fr* __restrict__ AH,
                                                       const Fr* __restrict__ BH, uint32_t ch, Fr* __restrict__ a3, Fr* __restrict__ partial) {
   extern __shared__ Fr tab[];  // L.total entries + 8 reduction slots
   Fr* red = tab + L.total;
@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(512) k_binp_rounds(const WordT* __restrict__ p
   Fr acc[7];
 #pragma unroll
   for (int i = 0; i < 7; i++) acc[i] = fr_zero();
-  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
+  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += zk_nblk * blockDim.x) {
     const uint32_t word = packed[g];
     const Fr w = fr_mul(AH[g & mh], BH[g >> ch]);
     Fr f[7];
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(512) k_binp_rounds(const WordT* __restrict__ p
   }
 }
 // proof[0..8] of the three packed rounds
-__global__ void __launch_bounds__(256) k_binp_finish(const Fr* __restrict__ partial, uint32_t nblk, Fr* __restrict__ proof) {
+__device__ __forceinline__ void k_binp_finish(uint32_t zk_nblk, const Fr* __restrict__ partial, uint32_t nblk, Fr* __restrict__ proof) {
   __shared__ Fr lds[4];
   for (uint32_t q = 0; q < 7; q++) {
     Fr acc = fr_zero();
@@ -168,14 +168,14 @@ __global__ void __launch_bounds__(256) k_binp_finish(const Fr* __restrict__ part
 // out[i] = sum_g eq(u_rec, g) * bit_i(word_g): FrTensor::partial_me(u_rec, nb) of the bit tensor.
 // grid (blocks, nb/8): blockIdx.y selects a group of 8 bit positions.  partial[(blk*NB/8 + grp)*8 + j]
 template <int NB, class WordT>
-__global__ void __launch_bounds__(256) k_binp_partial_me(const WordT* __restrict__ packed, uint32_t n, const Fr* __restrict__ A, const Fr* __restrict__ B, uint32_t c,
+__device__ __forceinline__ void k_binp_partial_me(uint32_t zk_nblk, const WordT* __restrict__ packed, uint32_t n, const Fr* __restrict__ A, const Fr* __restrict__ B, uint32_t c,
                                                           Fr* __restrict__ partial) {
   __shared__ Fr lds[4];
   const uint32_t grp = blockIdx.y, mask = (1u << c) - 1u;
   Fr acc[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) acc[j] = fr_zero();
-  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
+  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += zk_nblk * blockDim.x) {
     const uint32_t bits = ((uint32_t)packed[g] >> (8 * grp)) & 255u;
     if (!bits) continue;
     const Fr w = fr_mul(A[g & mask], B[g >> c]);
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256) k_binp_partial_me(const WordT* __restrict
     if (threadIdx.x == 0) partial[((uint64_t)blockIdx.x * (NB / 8) + grp) * 8 + j] = s;
   }
 }
-__global__ void __launch_bounds__(256) k_binp_partial_me_finish(const Fr* __restrict__ partial, uint32_t nblk, uint32_t nb, Fr* __restrict__ out) {
+__device__ __forceinline__ void k_binp_partial_me_finish(uint32_t zk_nblk, const Fr* __restrict__ partial, uint32_t nblk, uint32_t nb, Fr* __restrict__ out) {
   __shared__ Fr lds[4];
   for (uint32_t i = 0; i < nb; i++) {
     Fr acc = fr_zero();
@@ -198,9 +198,9 @@ __global__ void __launch_bounds__(256) k_binp_partial_me_finish(const Fr* __rest
     if (threadIdx.x == 0) out[i] = acc;
   }
 }
-__global__ void __launch_bounds__(256) k_eq_pair_tables(const Fr* __restrict__ u, uint32_t k, uint32_t c, Fr* __restrict__ A, Fr* __restrict__ B) {
+__device__ __forceinline__ void k_eq_pair_tables(uint32_t zk_nblk, const Fr* __restrict__ u, uint32_t k, uint32_t c, Fr* __restrict__ A, Fr* __restrict__ B) {
   const uint32_t nA = 1u << c, nB = 1u << (k - c);
-  for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nA + nB; idx += gridDim.x * blockDim.x) {
+  for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nA + nB; idx += zk_nblk * blockDim.x) {
     if (idx < nA) A[idx] = eq_prod(u, c, idx);
     else B[idx - nA] = eq_prod(u + c, k - c, idx - nA);
   }
@@ -218,7 +218,7 @@ int binp_sumcheck_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb, 
   ZK_ALLOC(ctx, AH, Fr, (size_t)1 << ch);
   ZK_ALLOC(ctx, BH, Fr, (size_t)1 << (kh - ch));
   const uint32_t nprep = L.total + (1u << ch) + (1u << (kh - ch));
-  ZK_LAUNCH(ctx, "binp_prep", 32ull * nprep, k_binp_prep, dim3(stream_grid(nprep, 256, 64)), dim3(256), 0, u_d, v_d, k, L, ch, tab.get(), AH.get(), BH.get());
+  ZK_LAUNCHB(ctx, "binp_prep", 32ull * nprep, 256, k_binp_prep, dim3(stream_grid(nprep, 256, 64)), 0, u_d, v_d, k, L, ch, tab.get(), AH.get(), BH.get());
   const uint32_t a3n = n * (nb / 8);
   ZK_ALLOC(ctx, a3, Fr, a3n);
   const uint32_t grid = stream_grid(n, 512, 256);
@@ -228,22 +228,22 @@ int binp_sumcheck_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb, 
   uint64_t bytes = (uint64_t)n * (nb / 8) + 32ull * a3n;
   if (nb == 32) {
     if (!attr32) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_binp_rounds<32, uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      zk::Kern<512, &k_binp_rounds<32, uint32_t>>::set_max_lds(lds);
       (void)hipGetLastError();
       attr32 = true;
     }
-    ZK_LAUNCH(ctx, "binp_rounds", bytes, (k_binp_rounds<32, uint32_t>), dim3(grid), dim3(512), lds, (const uint32_t*)packed, n, L, (const Fr*)tab.get(), (const Fr*)AH.get(),
+    ZK_LAUNCHB(ctx, "binp_rounds", bytes, 512, (k_binp_rounds<32, uint32_t>), dim3(grid), lds, (const uint32_t*)packed, n, L, (const Fr*)tab.get(), (const Fr*)AH.get(),
               (const Fr*)BH.get(), ch, a3.get(), partial.get());
   } else {
     if (!attr16) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_binp_rounds<16, uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      zk::Kern<512, &k_binp_rounds<16, uint16_t>>::set_max_lds(lds);
       (void)hipGetLastError();
       attr16 = true;
     }
-    ZK_LAUNCH(ctx, "binp_rounds", bytes, (k_binp_rounds<16, uint16_t>), dim3(grid), dim3(512), lds, (const uint16_t*)packed, n, L, (const Fr*)tab.get(), (const Fr*)AH.get(),
+    ZK_LAUNCHB(ctx, "binp_rounds", bytes, 512, (k_binp_rounds<16, uint16_t>), dim3(grid), lds, (const uint16_t*)packed, n, L, (const Fr*)tab.get(), (const Fr*)AH.get(),
               (const Fr*)BH.get(), ch, a3.get(), partial.get());
   }
-  ZK_LAUNCH(ctx, "binp_finish", 32ull * 7 * grid, k_binp_finish, dim3(1), dim3(256), 0, (const Fr*)partial.get(), grid, proof_d);
+  ZK_LAUNCHB(ctx, "binp_finish", 32ull * 7 * grid, 256, k_binp_finish, dim3(1), 0, (const Fr*)partial.get(), grid, proof_d);
   // rounds 3 .. k-1 and the final a(0): generic path on the 8x smaller table
   return sumcheck_bin_dev(ctx, a3.get(), a3n, u_d + 3, v_d + 3, k - 3, proof_d + 9);
 }
@@ -256,16 +256,16 @@ int binp_partial_me_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb
   ZK_ALLOC(ctx, A, Fr, (size_t)1 << c);
   ZK_ALLOC(ctx, B, Fr, (size_t)1 << (k - c));
   const uint32_t nt = (1u << c) + (1u << (k - c));
-  ZK_LAUNCH(ctx, "binp_prep", 32ull * nt, k_eq_pair_tables, dim3(stream_grid(nt, 256, 64)), dim3(256), 0, u_d, k, c, A.get(), B.get());
+  ZK_LAUNCHB(ctx, "binp_prep", 32ull * nt, 256, k_eq_pair_tables, dim3(stream_grid(nt, 256, 64)), 0, u_d, k, c, A.get(), B.get());
   const uint32_t grid = stream_grid(n, 256, 128);
   ZK_ALLOC(ctx, partial, Fr, (size_t)grid * nb);
   if (nb == 32)
-    ZK_LAUNCH(ctx, "binp_partial_me", 4ull * n, (k_binp_partial_me<32, uint32_t>), dim3(grid, 4), dim3(256), 0, (const uint32_t*)packed, n, (const Fr*)A.get(), (const Fr*)B.get(), c,
+    ZK_LAUNCHB(ctx, "binp_partial_me", 4ull * n, 256, (k_binp_partial_me<32, uint32_t>), dim3(grid, 4), 0, (const uint32_t*)packed, n, (const Fr*)A.get(), (const Fr*)B.get(), c,
               partial.get());
   else
-    ZK_LAUNCH(ctx, "binp_partial_me", 2ull * n, (k_binp_partial_me<16, uint16_t>), dim3(grid, 2), dim3(256), 0, (const uint16_t*)packed, n, (const Fr*)A.get(), (const Fr*)B.get(), c,
+    ZK_LAUNCHB(ctx, "binp_partial_me", 2ull * n, 256, (k_binp_partial_me<16, uint16_t>), dim3(grid, 2), 0, (const uint16_t*)packed, n, (const Fr*)A.get(), (const Fr*)B.get(), c,
               partial.get());
-  ZK_LAUNCH(ctx, "binp_finish", 32ull * grid * nb, k_binp_partial_me_finish, dim3(1), dim3(256), 0, (const Fr*)partial.get(), grid, nb, out_d);
+  ZK_LAUNCHB(ctx, "binp_finish", 32ull * grid * nb, 256, k_binp_partial_me_finish, dim3(1), 0, (const Fr*)partial.get(), grid, nb, out_d);
   return ZK_OK;
 }
 

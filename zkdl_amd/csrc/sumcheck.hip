@@ -44,9 +44,9 @@ __device__ __forceinline__ Fr eq_product(const Fr* __restrict__ u, uint32_t nvar
 // Weight tables of all big rounds in one launch.  w = weight challenges (u), k variables, split s:
 //   B[j]            = eq(w[s .. k), j)                      j < 2^(k-s)
 //   A[aoff(r) + j]  = eq(w[r+1 .. s), j)                    j < 2^(s-1-r),  r = 0 .. s-1,  aoff(r) = 2^s - 2^(s-r)
-__global__ void __launch_bounds__(256) k_sc_prep(const Fr* __restrict__ w, uint32_t k, uint32_t s, Fr* __restrict__ A, Fr* __restrict__ B) {
+__device__ __forceinline__ void k_sc_prep(uint32_t zk_nblk, const Fr* __restrict__ w, uint32_t k, uint32_t s, Fr* __restrict__ A, Fr* __restrict__ B) {
   const uint32_t nA = (1u << s) - 1u, nB = 1u << (k - s);
-  for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nA + nB; idx += gridDim.x * blockDim.x) {
+  for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nA + nB; idx += zk_nblk * blockDim.x) {
     if (idx < nA) {
       // level r holds 2^(s-1-r) entries at offset 2^s - 2^(s-r):  2^(s-r-1) < 2^s - idx <= 2^(s-r)
       uint32_t rem = (1u << s) - idx;  // >= 2
@@ -70,8 +70,8 @@ __global__ void __launch_bounds__(256) k_sc_prep(const Fr* __restrict__ w, uint3
 //   Aj / cj       : low weight table and its width for round r0 + j ; B the fixed high table
 //   partial[blk*3R + 3j + q], j < R, q < 3 ; prev_* : the previous launch's partials (3*prev_R per block)
 static uint32_t sc_multi_threshold(int R) {
-  static const uint32_t t3 = [] { const char* e = getenv("ZKDL_SC_R3_MIN"); return e ? (uint32_t)strtoul(e, nullptr, 0) : (1u << 22); }();
-  static const uint32_t t2 = [] { const char* e = getenv("ZKDL_SC_R2_MIN"); return e ? (uint32_t)strtoul(e, nullptr, 0) : (1u << 21); }();
+  static const uint32_t t3 = [] { const char* e = getenv("ZKDL_SC_R3_MIN"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xffffffffu; }();
+  static const uint32_t t2 = [] { const char* e = getenv("ZKDL_SC_R2_MIN"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xffffffffu; }();
   return R == 3 ? t3 : t2;
 }
 
@@ -80,7 +80,7 @@ struct ScLevels {
   uint32_t c[3];
 };
 template <int MODE, int R>
-__global__ void __launch_bounds__(256) k_sc_round(const Fr* __restrict__ a, const Fr* __restrict__ b, Fr* __restrict__ a_out, Fr* __restrict__ b_out,
+__device__ __forceinline__ void k_sc_round(uint32_t zk_nblk, const Fr* __restrict__ a, const Fr* __restrict__ b, Fr* __restrict__ a_out, Fr* __restrict__ b_out,
                                                    const Fr* __restrict__ fold, ScLevels lv, const Fr* __restrict__ B, uint32_t in_size, uint32_t out_size,
                                                    Fr* __restrict__ partial, const Fr* __restrict__ prev_partial, uint32_t prev_blocks, uint32_t prev_cols,
                                                    Fr* __restrict__ prev_dst) {
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(256) k_sc_round(const Fr* __restrict__ a, cons
   Fr acc[3 * R];
 #pragma clang loop unroll(full)
   for (int i = 0; i < 3 * R; i++) acc[i] = fr_zero();
-  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < out_size; g += gridDim.x * blockDim.x) {
+  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < out_size; g += zk_nblk * blockDim.x) {
     Fr va[NE], vb[MODE == SC_BIN ? 1 : NE];
     const uint64_t base = (uint64_t)g * NE;
 #pragma clang loop unroll(full)
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256) k_sc_round(const Fr* __restrict__ a, cons
 // fold = fold challenges (all k), w = weight challenges (all k) or nullptr for SC_IP.
 // Also closes the last big round (prev_*), and writes the final a(0) [, b(0)].
 template <int MODE>
-__global__ void __launch_bounds__(512) k_sc_tail(const Fr* __restrict__ a_in, const Fr* __restrict__ b_in, uint32_t n, const Fr* __restrict__ fold,
+__device__ __forceinline__ void k_sc_tail(uint32_t zk_nblk, const Fr* __restrict__ a_in, const Fr* __restrict__ b_in, uint32_t n, const Fr* __restrict__ fold,
                                                   const Fr* __restrict__ w, uint32_t k, uint32_t r0, Fr* __restrict__ proof,
                                                   const Fr* __restrict__ prev_partial, uint32_t prev_blocks, uint32_t prev_cols, Fr* __restrict__ prev_dst) {
   extern __shared__ Fr sm[];
@@ -272,7 +272,7 @@ static int run_sumcheck(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n,
       if (s > k) s = k;
       if (!tabA.alloc(ctx, (size_t)1 << s) || !tabB.alloc(ctx, (size_t)1 << (k - s))) return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: sumcheck weights");
       uint32_t tot = (1u << s) + (1u << (k - s));
-      ZK_LAUNCH(ctx, "sumcheck_prep", 32ull * tot, k_sc_prep, dim3(stream_grid(tot, 256, 256)), dim3(256), 0, weight_d, k, s, tabA.get(), tabB.get());
+      ZK_LAUNCHB(ctx, "sumcheck_prep", 32ull * tot, 256, k_sc_prep, dim3(stream_grid(tot, 256, 256)), 0, weight_d, k, s, tabA.get(), tabB.get());
     }
   }
   const Fr* a = a_in;
@@ -288,8 +288,9 @@ static int run_sumcheck(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n,
   Fr* prev_dst = nullptr;
   uint32_t launch = 0;
   for (uint32_t r = 0; r < nbig;) {
-    // Folding R rounds in one lane divides the lane count by 2^R: only worth it while the launch still
-    // fills the chip (thresholds measured on MI355X, overridable for sweeps).
+    // Folding R rounds in one lane divides the lane count by 2^R and needs ~2x the registers: measured on
+    // MI355X it never beat one round per launch on this workload (the rounds are VALU-bound, not HBM-bound),
+    // so it is off unless ZKDL_SC_R2_MIN / ZKDL_SC_R3_MIN set a size threshold.
     uint32_t R = 1;
     if (sz >= sc_multi_threshold(3)) R = 3;
     else if (sz >= sc_multi_threshold(2)) R = 2;
@@ -311,7 +312,7 @@ static int run_sumcheck(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n,
     Fr* part = partial.get() + (launch & 1) * 9 * SC_MAX_BLOCKS;
     uint64_t bytes = (two ? 2ull : 1ull) * 32ull * ((uint64_t)sz + osz);
 #define ZK_SC_LAUNCH(RR)                                                                                                                                   \
-  ZK_LAUNCH(ctx, tag, bytes, (k_sc_round<MODE, RR>), dim3(grid), dim3(256), 0, a, b, ao, bo, fold_d + r, lv, (const Fr*)tabB.get(), sz, osz, part, prev_partial, \
+  ZK_LAUNCHB(ctx, tag, bytes, 256, (k_sc_round<MODE, RR>), dim3(grid), 0, a, b, ao, bo, fold_d + r, lv, (const Fr*)tabB.get(), sz, osz, part, prev_partial, \
             prev_blocks, prev_cols, prev_dst)
     if (R == 3) ZK_SC_LAUNCH(3);
     else if (R == 2) ZK_SC_LAUNCH(2);
@@ -330,12 +331,12 @@ static int run_sumcheck(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n,
   size_t lds = ((MODE == SC_BIN ? 1 : 2) * SC_TAIL_N + SC_TAIL_N / 2 + 8) * sizeof(Fr);
   static bool lds_attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in on some runtimes
   if (!lds_attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sc_tail<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    zk::Kern<512, &k_sc_tail<MODE>>::set_max_lds(lds);
     (void)hipGetLastError();
     lds_attr_set = true;
   }
   const char* ttag = MODE == SC_IP ? "sumcheck_ip_tail" : MODE == SC_HP ? "sumcheck_hp_tail" : "sumcheck_bin_tail";
-  ZK_LAUNCH(ctx, ttag, (two ? 2ull : 1ull) * 32ull * sz, k_sc_tail<MODE>, dim3(1), dim3(512), lds, a, b, sz, fold_d, weight_d, k, nbig, proof_d, prev_partial, prev_blocks, prev_cols, prev_dst);
+  ZK_LAUNCHB(ctx, ttag, (two ? 2ull : 1ull) * 32ull * sz, 512, k_sc_tail<MODE>, dim3(1), lds, a, b, sz, fold_d, weight_d, k, nbig, proof_d, prev_partial, prev_blocks, prev_cols, prev_dst);
   return ZK_OK;
 }
 
