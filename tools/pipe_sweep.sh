@@ -5,7 +5,8 @@ d=json.loads(open('gpurun_out/sw.log').read().strip().split('\n')[-1])
 k=d['kernels']
 print(sys.argv[1], round(d['ms_per_step'],2), round(d['host_enqueue_ms_per_step'],2), d['aggregate_fr'][:14], 'launches', sum(v['launches_per_step'] for v in k.values()))
 " "$1"; }
-run "batched pipelined" ""
-run "batched nopipe" "--no-pipeline"
-cp gpurun_out/sw.log gpurun_out/bench_batched_nopipe.log
-ITERS=5 timeout -k 10 200 python tools/host_probe.py 2>&1 | grep "iter [1-4]" | cut -c1-220
+run "groups pipelined" ""
+run "groups nopipe" "--no-pipeline"
+GPU_MAX_HW_QUEUES=8 run "groups pipelined hwq8" ""
+ITERS=4 timeout -k 10 200 python tools/host_probe.py 2>&1 | grep "iter [12]" | cut -c1-220
+ZKDL_PROF_TRACE=gpurun_out/trace_g.csv timeout -k 10 200 python tools/trace_probe.py

@@ -73,8 +73,12 @@ struct RecOp {
   size_t args_off = 0;  // JobRec image inside Recorder::args
   std::function<int(hipStream_t)> opaque;
 };
+struct RecChain {
+  uint32_t group = 0;  // chains of one group are zipped together and run on that group's stream
+  std::vector<RecOp> ops;
+};
 struct Recorder {
-  std::vector<std::vector<RecOp>> chains;  // one per prove call, in call order
+  std::vector<RecChain> chains;            // independent dependency chains, in recording order
   std::vector<uint8_t> args;               // JobRec images of all recorded launches
   std::vector<uint8_t> blob;               // host image of the device blob: small uploads, then the job tables
   uint8_t* blob_dev = nullptr;
@@ -83,8 +87,12 @@ struct Recorder {
   bool empty() const { return chains.empty(); }
 };
 static constexpr size_t REC_BLOB_CAP = 4u << 20;
+// groups (= streams) the layers' independent pieces are spread over, balanced on the 18M-parameter MLP:
+// FC sumcheck + Z(u) | FC opening + ReLU Hadamard sumcheck | ReLU magnitude bits | ReLU remainder bits + partial_me's
+enum { REC_GROUP_FC_A = 0, REC_GROUP_FC_OPEN = 1, REC_GROUP_RELU_MAG = 2, REC_GROUP_RELU_REM = 3 };
 
-int rec_begin_chain(zk_ctx* ctx, Recorder* r);             // sets ctx->rec; allocates the blob on first use
+int rec_begin_chain(zk_ctx* ctx, Recorder* r, uint32_t group = 0);  // sets ctx->rec; allocates the blob on first use
+void rec_split(zk_ctx* ctx, uint32_t group);              // recording: what follows is independent of what came before
 void rec_end_chain(zk_ctx* ctx);                           // clears ctx->rec
 int rec_execute(zk_ctx* ctx, Recorder* r);                 // zip + launch on ctx->stream, release temporaries
 void* rec_blob_put(zk_ctx* ctx, const void* src, size_t bytes);  // -> DEVICE address inside the blob
@@ -95,9 +103,9 @@ struct RecScope {
   zk_ctx* ctx;
   bool on = false;
   int rc = ZK_OK;
-  RecScope(zk_ctx* c, Recorder* r) : ctx(c) {
+  RecScope(zk_ctx* c, Recorder* r, uint32_t group) : ctx(c) {
     if (!c->batch_layers || c->rec || c->stream != c->main_stream) return;
-    rc = rec_begin_chain(c, r);
+    rc = rec_begin_chain(c, r, group);
     on = rc == ZK_OK;
   }
   ~RecScope() {
@@ -137,7 +145,7 @@ struct Kern<N, Body, void (*)(uint32_t, A...)> {
       Job j{grid.x, 0u, make_pack(a...)};
       const uint8_t* src = reinterpret_cast<const uint8_t*>(&j);
       r->args.insert(r->args.end(), src, src + sizeof(Job));
-      r->chains.back().push_back(std::move(op));
+      r->chains.back().ops.push_back(std::move(op));
       return ZK_OK;
     }
     {

@@ -288,7 +288,7 @@ int fc_prove(zk_ctx* ctx, zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint
   G1J* const g1_slot = tr->g1_d + tr->n_g1;
   tr->n_fr += add_fr;
   tr->n_g1 += add_g1;
-  RecScope recording(ctx, &tr->rec);  // batching on: this call only records its launches (one chain)
+  RecScope recording(ctx, &tr->rec, REC_GROUP_FC_A);  // batching on: this call only records its launches
   if (recording.rc != ZK_OK) return recording.rc;
   LaneScope lane(ctx, recording.on ? ~0u : fc->serial);  // declared before every temporary: they are released while the lane is current
 
@@ -313,12 +313,15 @@ int fc_prove(zk_ctx* ctx, zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint
   // a = X.partial_me(u_bs, in) ; b = W.partial_me(u_out, 1)
   ZK_ALLOC(ctx, a, Fr, asz);
   ZK_ALLOC(ctx, b, Fr, bsz);
+  // three independent pieces (recorded as separate chains): the inner-product sumcheck, Z(u_Z), the opening
   ZK_TRY(fr_partial_me_dev(ctx, x, xn, u_bs, k_bs, fc->in, a.get()));
   ZK_TRY(fr_partial_me_dev(ctx, fc->weights, wn, u_out, k_out, 1, b.get()));
   ZK_TRY(sumcheck_ip_dev(ctx, a.get(), b.get(), asz, u_in, k_in, fr_slot));
   // Z(u_Z)
+  rec_split(ctx, REC_GROUP_FC_A);
   ZK_TRY(fr_me_dev(ctx, z, zn, uz.get(), k_out + k_bs, fr_slot + 3 * k_in + 2));
   // generators.open(weights, com, u_out || u_in)
+  rec_split(ctx, REC_GROUP_FC_OPEN);
   ZK_TRY(open_dev(ctx, gens, fc->weights, wn, fc->com, u_out, k_out + k_in, g1_slot, g1_slot + 1, fr_slot + 3 * k_in + 3, &tr->queue));
   return ZK_OK;
 }
@@ -359,7 +362,7 @@ int relu_prove(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const Fr* z, uint3
   ZK_TRY(tr->ensure(add_fr, 0));
   Fr* out = tr->fr_d + tr->n_fr;
   tr->n_fr += add_fr;
-  RecScope recording(ctx, &tr->rec);
+  RecScope recording(ctx, &tr->rec, REC_GROUP_RELU_MAG);
   if (recording.rc != ZK_OK) return recording.rc;
   LaneScope lane(ctx, recording.on ? ~0u : relu->serial);  // declared before every temporary
 
@@ -379,10 +382,13 @@ int relu_prove(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const Fr* z, uint3
   if (ctx->relu_packed) {
     ZK_TRY(binp_sumcheck_dev(ctx, relu->mag_packed, n, 32, c + offs[0], c + offs[1], k + 5, out));
     out += 3 * (k + 5) + 1;
+    rec_split(ctx, REC_GROUP_RELU_REM);  // the five pieces are independent: separate chains, spread over the groups
     ZK_TRY(binp_partial_me_dev(ctx, relu->mag_packed, n, 32, c + offs[4], k, out));
     out += 32;
+    rec_split(ctx, REC_GROUP_RELU_REM);
     ZK_TRY(binp_sumcheck_dev(ctx, relu->rem_packed, n, 16, c + offs[2], c + offs[3], k + 4, out));
     out += 3 * (k + 4) + 1;
+    rec_split(ctx, REC_GROUP_RELU_REM);
     ZK_TRY(binp_partial_me_dev(ctx, relu->rem_packed, n, 16, c + offs[4], k, out));
     out += 16;
   } else {
@@ -395,6 +401,7 @@ int relu_prove(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const Fr* z, uint3
     ZK_TRY(fr_partial_me_dev(ctx, relu->rem_bin, n * 16, c + offs[4], k, 16, out));
     out += 16;
   }
+  rec_split(ctx, REC_GROUP_FC_OPEN);
   ZK_TRY(sumcheck_hp_dev(ctx, x, relu->sign, n, c + offs[5], c + offs[6], k, out));
   return ZK_OK;
 }

@@ -7,7 +7,7 @@
 
 namespace zk {
 
-int rec_begin_chain(zk_ctx* ctx, Recorder* r) {
+int rec_begin_chain(zk_ctx* ctx, Recorder* r, uint32_t group) {
   if (!r->blob_dev) {
     r->blob_dev = static_cast<uint8_t*>(ctx->pool_alloc(REC_BLOB_CAP));
     if (!r->blob_dev) return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: recorder blob");
@@ -16,8 +16,16 @@ int rec_begin_chain(zk_ctx* ctx, Recorder* r) {
   }
   if (r->chains.empty()) ctx->pending_recs.push_back(r);
   r->chains.emplace_back();
+  r->chains.back().group = group;
   ctx->rec = r;
   return ZK_OK;
+}
+
+void rec_split(zk_ctx* ctx, uint32_t group) {
+  Recorder* r = ctx->rec;
+  if (!r) return;
+  if (!r->chains.back().ops.empty()) r->chains.emplace_back();
+  r->chains.back().group = group;
 }
 
 void rec_end_chain(zk_ctx* ctx) { ctx->rec = nullptr; }
@@ -37,7 +45,7 @@ int rec_opaque(zk_ctx* ctx, const char* name, uint64_t bytes, std::function<int(
   op.name = name;
   op.bytes = bytes;
   op.opaque = std::move(fn);
-  ctx->rec->chains.back().push_back(std::move(op));
+  ctx->rec->chains.back().ops.push_back(std::move(op));
   return ZK_OK;
 }
 
@@ -47,7 +55,9 @@ struct Batch {
   dim3 grid;
   size_t table_off;  // job table inside the blob
   uint64_t bytes;
+  uint32_t group;
 };
+inline bool same_key(const RecOp& a, const RecOp& b) { return a.k && b.k == a.k && b.gy == a.gy && b.shmem == a.shmem; }
 }  // namespace
 
 int rec_execute(zk_ctx* ctx, Recorder* r) {
@@ -57,74 +67,73 @@ int rec_execute(zk_ctx* ctx, Recorder* r) {
   auto it = std::find(ctx->pending_recs.begin(), ctx->pending_recs.end(), r);
   if (it != ctx->pending_recs.end()) ctx->pending_recs.erase(it);
 
-  // ---- zip: repeatedly take the largest group of chain heads that launch the same kernel
+  // ---- zip, group by group: the chain with the most launches left picks the kernel (so a chain that fell
+  // behind -- one round fewer, a different variant -- catches up instead of trailing to the end), and every
+  // other chain of the group whose head is the same kernel joins that launch
   const size_t nc = r->chains.size();
   std::vector<size_t> head(nc, 0);
   std::vector<Batch> batches;
-  size_t remaining = 0;
-  for (auto& c : r->chains) remaining += c.size();
+  std::vector<uint32_t> groups;
+  for (auto& c : r->chains)
+    if (std::find(groups.begin(), groups.end(), c.group) == groups.end()) groups.push_back(c.group);
+  std::sort(groups.begin(), groups.end());
   int rc = ZK_OK;
   std::vector<size_t> members;
-  while (remaining) {
-    // pick the key of the earliest chain's head unless another key has strictly more members
-    size_t best = nc, best_count = 0;
-    for (size_t c = 0; c < nc; c++) {
-      if (head[c] >= r->chains[c].size()) continue;
-      const RecOp& a = r->chains[c][head[c]];
-      size_t count = 1;
-      if (a.k)
-        for (size_t d = c + 1; d < nc; d++) {
-          if (head[d] >= r->chains[d].size()) continue;
-          const RecOp& b = r->chains[d][head[d]];
-          if (b.k == a.k && b.gy == a.gy && b.shmem == a.shmem) count++;
+  for (uint32_t g : groups) {
+    for (;;) {
+      size_t best = nc, best_left = 0;
+      for (size_t c = 0; c < nc; c++) {
+        if (r->chains[c].group != g) continue;
+        size_t left = r->chains[c].ops.size() - head[c];
+        if (left > best_left) {
+          best = c;
+          best_left = left;
         }
-      if (count > best_count) {
-        best = c;
-        best_count = count;
       }
-    }
-    const RecOp& a = r->chains[best][head[best]];
-    Batch b;
-    b.first = &a;
-    b.bytes = 0;
-    b.table_off = 0;
-    if (!a.k) {
-      b.grid = dim3(1);
-      head[best]++;
-      remaining--;
+      if (best == nc) break;
+      const RecOp& a = r->chains[best].ops[head[best]];
+      Batch b;
+      b.first = &a;
+      b.bytes = 0;
+      b.table_off = 0;
+      b.group = g;
+      if (!a.k) {
+        b.grid = dim3(1);
+        head[best]++;
+        batches.push_back(b);
+        continue;
+      }
+      members.clear();
+      uint32_t gx = 0;
+      for (size_t d = 0; d < nc; d++) {
+        if (r->chains[d].group != g || head[d] >= r->chains[d].ops.size()) continue;
+        const RecOp& o = r->chains[d].ops[head[d]];
+        if (same_key(a, o)) {
+          members.push_back(d);
+          gx = std::max(gx, o.gx);
+          b.bytes += o.bytes;
+        }
+      }
+      size_t off = (r->blob.size() + 63) & ~(size_t)63;
+      size_t need = (size_t)a.k->job_size * members.size();
+      if (off + need > r->blob_cap) {
+        rc = ctx->fail(ZK_ERR_ALLOC, "recorder blob exhausted");
+        break;
+      }
+      r->blob.resize(off + need);
+      for (size_t m = 0; m < members.size(); m++) {
+        const RecOp& o = r->chains[members[m]].ops[head[members[m]]];
+        memcpy(r->blob.data() + off + m * a.k->job_size, r->args.data() + o.args_off, a.k->job_size);
+        head[members[m]]++;
+      }
+      b.table_off = off;
+      b.grid = dim3(gx, a.gy, (uint32_t)members.size());
       batches.push_back(b);
-      continue;
     }
-    members.clear();
-    uint32_t gx = 0;
-    for (size_t d = best; d < nc; d++) {
-      if (head[d] >= r->chains[d].size()) continue;
-      const RecOp& o = r->chains[d][head[d]];
-      if (o.k == a.k && o.gy == a.gy && o.shmem == a.shmem) {
-        members.push_back(d);
-        gx = std::max(gx, o.gx);
-        b.bytes += o.bytes;
-      }
-    }
-    size_t off = (r->blob.size() + 63) & ~(size_t)63;
-    size_t need = (size_t)a.k->job_size * members.size();
-    if (off + need > r->blob_cap) {
-      rc = ctx->fail(ZK_ERR_ALLOC, "recorder blob exhausted");
-      break;
-    }
-    r->blob.resize(off + need);
-    for (size_t m = 0; m < members.size(); m++) {
-      const RecOp& o = r->chains[members[m]][head[members[m]]];
-      memcpy(r->blob.data() + off + m * a.k->job_size, r->args.data() + o.args_off, a.k->job_size);
-      head[members[m]]++;
-    }
-    remaining -= members.size();
-    b.table_off = off;
-    b.grid = dim3(gx, a.gy, (uint32_t)members.size());
-    batches.push_back(b);
+    if (rc != ZK_OK) break;
   }
 
-  // ---- upload the blob (uploads + job tables) through the pinned staging ring, then launch
+  // ---- upload the blob (uploads + job tables) through the pinned staging ring
   if (rc == ZK_OK) {
     const size_t total = r->blob.size(), step = 1u << 20;
     for (size_t o = 0; o < total && rc == ZK_OK; o += step) {
@@ -133,14 +142,35 @@ int rec_execute(zk_ctx* ctx, Recorder* r) {
       rc = st ? dev_copy(ctx, r->blob_dev + o, st, (nb + 15) & ~(size_t)15) : ctx->fail(ZK_ERR_ALLOC, "pinned staging exhausted");
     }
   }
+  // ---- launch: group 0 on the current stream, group g > 0 on worker lane g-1 (forked behind the upload)
+  hipStream_t home = ctx->stream;
+  const bool fan_out = ctx->lanes_enabled && !ctx->lanes.empty() && home == ctx->main_stream;
+  std::vector<zk_ctx::Lane*> used;
+  if (fan_out) {  // fork first, so that no group waits for another group's launches
+    (void)hipEventRecord(ctx->fork_ev, home);
+    for (uint32_t g : groups) {
+      if (g == 0) continue;
+      zk_ctx::Lane* l = &ctx->lanes[(g - 1) % ctx->lanes.size()];
+      if (std::find(used.begin(), used.end(), l) != used.end()) continue;
+      (void)hipStreamWaitEvent(l->stream, ctx->fork_ev, 0);
+      used.push_back(l);
+    }
+  }
+  auto stream_of = [&](uint32_t g) -> hipStream_t { return (g == 0 || !fan_out) ? home : ctx->lanes[(g - 1) % ctx->lanes.size()].stream; };
   for (size_t i = 0; i < batches.size() && rc == ZK_OK; i++) {
     const Batch& b = batches[i];
+    ctx->stream = stream_of(b.group);
     int lr;
     {
       ProfScope ps(ctx, b.first->name, b.first->k ? b.bytes : b.first->bytes);
       lr = b.first->k ? b.first->k->launch_many(ctx->stream, b.grid, b.first->shmem, r->blob_dev + b.table_off) : b.first->opaque(ctx->stream);
     }
     if (lr != 0) rc = ctx->fail(ZK_ERR_DEVICE, std::string("launch of ") + b.first->name + " failed: " + hipGetErrorString(hipGetLastError()));
+  }
+  ctx->stream = home;
+  for (zk_ctx::Lane* l : used) {  // join: everything after this on the home stream sees the groups' results
+    (void)hipEventRecord(l->done, l->stream);
+    (void)hipStreamWaitEvent(home, l->done, 0);
   }
 
   // ---- temporaries of the recorded calls: stream-ordered release behind the launches above
