@@ -3,10 +3,8 @@ python3 -c "
 import json,sys
 d=json.loads(open('gpurun_out/sw.log').read().strip().split('\n')[-1])
 k=d['kernels']
-print(sys.argv[1], round(d['ms_per_step'],2), round(d['host_enqueue_ms_per_step'],2), d['aggregate_fr'][:14], 'launches', sum(v['launches_per_step'] for v in k.values()))
+print(sys.argv[1], round(d['ms_per_step'],2), round(d['host_enqueue_ms_per_step'],2), d['aggregate_fr'][:14], {n[4:]:round(k[n]['ms_per_step'],2) for n in k if n.startswith('msm_') or n.startswith('g1_c')})
 " "$1"; }
-run "groups pipelined" ""
-run "groups nopipe" "--no-pipeline"
-GPU_MAX_HW_QUEUES=8 run "groups pipelined hwq8" ""
-ITERS=4 timeout -k 10 200 python tools/host_probe.py 2>&1 | grep "iter [12]" | cut -c1-220
-ZKDL_PROF_TRACE=gpurun_out/trace_g.csv timeout -k 10 200 python tools/trace_probe.py
+run "pipelined" ""
+ZKDL_G1_STREAMS=2 run "g1s=2" ""
+run "nopipe" "--no-pipeline"

@@ -15,7 +15,7 @@ path = os.environ.get("ZKDL_PROF_TRACE")
 if path and os.path.exists(path): os.remove(path)
 zk.prof_reset(); zk.prof_enable(True)
 pipelined = os.environ.get("PIPE", "0") == "1"
-for it in range(3 if pipelined else 1):
+for it in range(4 if pipelined else 1):
     tr = wl.trs[it & 1]
     wl.prove(wl.challenges(10 + it), tr)
     if pipelined: tr.seal()

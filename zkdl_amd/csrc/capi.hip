@@ -150,7 +150,7 @@ int zk_ctx_create(int device, zk_ctx** out) {
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     int prio = g1_prio < 0 ? least : g1_prio > 0 ? greatest : (least + greatest) / 2;
     {
-      int ng = 1;
+      int ng = 2;
       if (const char* e = getenv("ZKDL_G1_STREAMS")) ng = atoi(e);
       ng = ng < 0 ? 0 : ng > 4 ? 4 : ng;
       ctx->g1_lanes.resize((size_t)ng);

@@ -311,33 +311,88 @@ __global__ void __launch_bounds__(64) k_msm_combine(const MsmJob* __restrict__ j
   *dst = acc;
 }
 
-// U[q*c + i] = sum of buckets b (1..B) whose index has bit i set; grid (c, jobs), LDS tree
-template <int T>
-__global__ void __launch_bounds__(T) k_msm_bits(const G1J* __restrict__ buckets, uint32_t c, G1J* __restrict__ U) {
-  __shared__ G1J s[T];
+// ---- bucket reduction  out[q] = sum_{b=1..B} b * S_b  without a running-sum chain and without idle lanes.
+// Write b = hi * 2^LB + lo.  Then  sum_b b*S_b = sum_lo lo*C_lo + 2^LB * sum_hi hi*R_hi  with the row sums
+// R_hi = sum_lo S_b and column sums C_lo = sum_hi S_b: 2B additions instead of the (c/2)*B of summing one
+// bit-slice of the bucket index at a time over all buckets.  The two small weighted sums (2^LB and B/2^LB + 1
+// terms) are then taken bit-slice by bit-slice: T_j, j < c, and out = sum_j 2^j T_j.
+// Both kernels keep every lane busy with a short sequential run of additions and use few waves, so they
+// share the machine with the next proof's Fr work instead of parking thousands of barrier-bound waves on it.
+__device__ __forceinline__ G1J g1_shfl_xor(const G1J& p, int mask) {
+  G1J r;
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    r.x.v[i] = __shfl_xor(p.x.v[i], mask, 64);
+    r.y.v[i] = __shfl_xor(p.y.v[i], mask, 64);
+    r.z.v[i] = __shfl_xor(p.z.v[i], mask, 64);
+  }
+  return r;
+}
+struct ReduceShape {
+  uint32_t LB, nlo, nhi, nsums;  // sums 0..nhi-1: rows, nhi..nhi+nlo-1: columns
+};
+static ReduceShape reduce_shape(uint32_t c) {
+  ReduceShape s;
+  s.LB = c / 2;  // c = 10: 32 columns x 17 rows
+  s.nlo = 1u << s.LB;
+  s.nhi = ((1u << (c - 1)) >> s.LB) + 1u;
+  s.nsums = s.nhi + s.nlo;
+  return s;
+}
+// RC[q*nsums + s]: four lanes per sum, each adds every fourth term, then two butterfly steps.  grid (blocks, jobs)
+__global__ void __launch_bounds__(64) k_msm_rowcol(const G1J* __restrict__ buckets, uint32_t c, ReduceShape sh, G1J* __restrict__ RC) {
   const uint32_t B = 1u << (c - 1);
-  const uint32_t i = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;
+  const uint32_t q = blockIdx.y;
+  const uint32_t lane = blockIdx.x * 64u + threadIdx.x;
+  const uint32_t s = lane >> 2, t = lane & 3u;
   const G1J* bk = buckets + (uint64_t)q * B;
   G1J acc = g1_zero();
-  for (uint32_t b = tid + 1; b <= B; b += T)
-    if ((b >> i) & 1u) acc = g1_add(acc, bk[b - 1]);
-  s[tid] = acc;
+  if (s < sh.nhi) {  // row hi = s
+    for (uint32_t lo = t; lo < sh.nlo; lo += 4) {
+      uint32_t b = s * sh.nlo + lo;
+      if (b >= 1 && b <= B) acc = g1_add(acc, bk[b - 1]);
+    }
+  } else if (s < sh.nsums) {  // column lo = s - nhi
+    const uint32_t lo = s - sh.nhi;
+    for (uint32_t hi = t; hi < sh.nhi; hi += 4) {
+      uint32_t b = hi * sh.nlo + lo;
+      if (b >= 1 && b <= B) acc = g1_add(acc, bk[b - 1]);
+    }
+  }
+  acc = g1_add(acc, g1_shfl_xor(acc, 1));
+  acc = g1_add(acc, g1_shfl_xor(acc, 2));
+  if (s < sh.nsums && t == 0) RC[(uint64_t)q * sh.nsums + s] = acc;
+}
+// one wave per job: lanes 4j..4j+3 build slice T_j, lane j then doubles it j times, and a 4-level tree adds them
+__global__ void __launch_bounds__(64) k_msm_weighted(const MsmJob* __restrict__ jobs, const G1J* __restrict__ RC, uint32_t c, ReduceShape sh) {
+  __shared__ G1J T[16];
+  const uint32_t q = blockIdx.x, lane = threadIdx.x;
+  const uint32_t j = lane >> 2, t = lane & 3u;
+  const G1J* rc = RC + (uint64_t)q * sh.nsums;
+  G1J acc = g1_zero();
+  if (j < sh.LB) {  // column weights: bit j of lo
+    for (uint32_t lo = t; lo < sh.nlo; lo += 4)
+      if ((lo >> j) & 1u) acc = g1_add(acc, rc[sh.nhi + lo]);
+  } else if (j < c) {  // row weights: bit j - LB of hi
+    for (uint32_t hi = t; hi < sh.nhi; hi += 4)
+      if ((hi >> (j - sh.LB)) & 1u) acc = g1_add(acc, rc[hi]);
+  }
+  acc = g1_add(acc, g1_shfl_xor(acc, 1));
+  acc = g1_add(acc, g1_shfl_xor(acc, 2));
+  if (t == 0 && j < 16) T[j] = j < c ? acc : g1_zero();
   __syncthreads();
-  for (uint32_t st = T / 2; st > 0; st >>= 1) {
-    if (tid < st) s[tid] = g1_add(s[tid], s[tid + st]);
+  if (lane < 16) {
+    acc = T[lane];
+    const uint32_t nd = lane < c ? lane : 0;  // lanes >= c hold infinity
+    for (uint32_t d = 0; d < nd; d++) acc = g1_double(acc);
+    T[lane] = acc;
+  }
+  __syncthreads();
+  for (uint32_t st = 8; st > 0; st >>= 1) {
+    if (lane < st) T[lane] = g1_add(T[lane], T[lane + st]);
     __syncthreads();
   }
-  if (tid == 0) U[(uint64_t)q * c + i] = s[0];
-}
-
-// out[q] = sum_i 2^i U[q][i]
-__global__ void __launch_bounds__(64) k_msm_horner(const MsmJob* __restrict__ jobs, const G1J* __restrict__ U, uint32_t c, uint32_t q_total) {
-  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= q_total) return;
-  const G1J* u = U + (uint64_t)q * c;
-  G1J acc = u[c - 1];
-  for (int i = (int)c - 2; i >= 0; i--) acc = g1_add(g1_double(acc), u[i]);
-  *jobs[q].out = acc;
+  if (lane == 0) *jobs[q].out = T[0];
 }
 
 // canonical form in place: affine x, y with Z = ONE; infinity as {0, ONE, 0}
@@ -413,16 +468,16 @@ int msm_run_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs, uint32_t c) 
   ZK_ALLOC(ctx, buckets, G1J, (size_t)nj * B);
   ZK_ALLOC(ctx, head, G1J, chunks);
   ZK_ALLOC(ctx, tail, G1J, chunks);
-  ZK_ALLOC(ctx, U, G1J, (size_t)nj * c);
+  ZK_ALLOC(ctx, RC, G1J, (size_t)nj * reduce_shape(c).nsums);
   size_t lds = (size_t)(B + 2 + 1024) * 4;
   ZK_LAUNCH(ctx, "msm_sort", 32ull * pairs + 4ull * items, k_msm_sort, dim3(nj), dim3(1024), lds, (const MsmJob*)djobs.get(), c, K, idx.get(), off.get());
   ZK_LAUNCH(ctx, "msm_accum", 100ull * items, k_msm_accum, dim3((max_chunks + 63) / 64, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, (const uint32_t*)idx.get(),
             (const uint32_t*)off.get(), buckets.get(), head.get(), tail.get());
   ZK_LAUNCH(ctx, "msm_combine", 144ull * nj * B, k_msm_combine, dim3((B + 63) / 64, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, (const uint32_t*)off.get(), buckets.get(),
             (const G1J*)head.get(), (const G1J*)tail.get());
-  if (B >= 512) ZK_LAUNCH(ctx, "msm_bucket_reduce", 144ull * nj * B, k_msm_bits<256>, dim3(c, nj), dim3(256), 0, (const G1J*)buckets.get(), c, U.get());
-  else ZK_LAUNCH(ctx, "msm_bucket_reduce", 144ull * nj * B, k_msm_bits<64>, dim3(c, nj), dim3(64), 0, (const G1J*)buckets.get(), c, U.get());
-  ZK_LAUNCH(ctx, "msm_horner", 144ull * nj * c, k_msm_horner, dim3((nj + 63) / 64), dim3(64), 0, (const MsmJob*)djobs.get(), (const G1J*)U.get(), c, nj);
+  const ReduceShape sh = reduce_shape(c);
+  ZK_LAUNCH(ctx, "msm_bucket_reduce", 144ull * nj * B, k_msm_rowcol, dim3((sh.nsums * 4 + 63) / 64, nj), dim3(64), 0, (const G1J*)buckets.get(), c, sh, RC.get());
+  ZK_LAUNCH(ctx, "msm_horner", 144ull * nj * sh.nsums, k_msm_weighted, dim3(nj), dim3(64), 0, (const MsmJob*)djobs.get(), (const G1J*)RC.get(), c, sh);
   return ZK_OK;
 }
 
