@@ -192,11 +192,12 @@ def cpu_baseline(zk, wl, max_seconds=60.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="mlp18m_b256", choices=sorted(WORKLOADS))
     ap.add_argument("--msm", default="pippenger", choices=["pippenger", "literal"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="no worker streams at all: every launch runs alone (the schedule the roofline durations are measured under)")
     ap.add_argument("--msm-window", type=int, default=0, help="force the Pippenger window width (0 = library default)")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every proof on the main stream (no overlap of proof i's G1 phase with proof i+1's Fr phase)")
     ap.add_argument("--backend", default=os.environ.get("BENCH_BACKEND", "nccl"), help="nccl (= RCCL, default) | gloo (rehearsal on one GPU)")
@@ -230,7 +231,9 @@ def main():
 
     # The G1 phase of every proof (MSM batch, canonicalisation, digest) and the all-reduce of its digest are
     # ordered on the library's G1 stream; the Fr phase of the next proof runs beside them on the worker lanes.
-    pipelined = not args.no_pipeline
+    pipelined = not args.no_pipeline and not args.serial
+    if args.serial:
+        zk.set_flag("lanes", 0)
     aggs = [torch.zeros(8, dtype=torch.int64, device="cuda") for _ in range(2)]
     ext_streams = {}
     torch.cuda.synchronize()
@@ -283,22 +286,38 @@ def main():
     value = ms_per_step / (batch * world)
     aggregate = lanes_to_fr(agg.cpu().tolist())
 
-    # ---- per-kernel device time over the same steps (HIP events on the library's stream)
-    zk.prof_reset()
-    zk.prof_enable(True)
+    # ---- per-kernel device time (HIP events on the launching stream).  Two passes over the same steps:
+    #  * standalone: worker streams off, so every launch runs alone on the chip -- this is the duration a
+    #    roofline can be read from (rocprofv3 of `bench.py --serial` reproduces it);
+    #  * concurrent: the timed region's schedule (4 Fr groups + G1 streams overlapping), where a launch's
+    #    duration includes the time it shares the chip with others.
     nprof = max(1, min(args.steps, 2))
-    for i in range(nprof):
-        step(10_000 + i)
-    zk.sync()
-    prof = zk.prof_read()
-    zk.prof_enable(False)
+
+    def profile_pass(serial):
+        zk.set_flag("lanes", 0 if serial else 1)
+        zk.prof_reset()
+        zk.prof_enable(True)
+        for i in range(nprof):
+            step(10_000 + i)
+        zk.sync()
+        p = zk.prof_read()
+        zk.prof_enable(False)
+        zk.set_flag("lanes", 0 if args.serial else 1)
+        return p
+
+    prof_conc = profile_pass(serial=False) if not args.serial else {}
+    prof = profile_pass(serial=True)
     total_ms = sum(v["ms"] for v in prof.values()) or 1.0
     kernels = {k: {"ms_per_step": v["ms"] / nprof, "share": v["ms"] / total_ms, "launches_per_step": v["launches"] // nprof,
-                   "alg_GBps": (v["bytes"] / v["ms"] / 1e6) if v["ms"] > 0 else 0.0} for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+                   "alg_GBps": (v["bytes"] / v["ms"] / 1e6) if v["ms"] > 0 else 0.0,
+                   "concurrent_ms_per_step": (prof_conc[k]["ms"] / nprof) if k in prof_conc else None} for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
     # roofline for the dominant HBM-streaming kernel family of the timed region.  achieved = algorithmic
     # bytes per launch / average launch duration (HIP events on the launching stream).
-    hbm_families = {"sumcheck_bin_round": "void zk::k_sc_round<2>", "sumcheck_hp_round": "void zk::k_sc_round<1>", "sumcheck_ip_round": "void zk::k_sc_round<0>",
-                    "fr_contract": "zk::k_colsum", "binp_rounds": "void zk::k_binp_rounds<32, unsigned int>", "fr_fold": "zk::k_fr_fold"}
+    # family -> substrings that identify its kernel in rocprofv3's names: the batched launch form is
+    # k_many<N, &body, ...>, which rocprofv3 prints mangled (_ZN2zk6k_manyILi256ETnDaXadL_ZNS_10k_sc_roundILi2ELi1EEE...)
+    hbm_families = {"sumcheck_bin_round": ["k_many", "k_sc_roundILi2ELi1E"], "sumcheck_hp_round": ["k_many", "k_sc_roundILi1ELi1E"],
+                    "sumcheck_ip_round": ["k_many", "k_sc_roundILi0ELi1E"], "fr_contract": ["k_many", "k_colsum"],
+                    "binp_rounds": ["k_many", "k_binp_roundsILi32E"], "fr_fold": ["k_many", "k_fr_fold"]}
     cands = [k for k in kernels if k in hbm_families] or list(kernels)[:1]
     dom = max(cands, key=lambda k: kernels[k]["ms_per_step"])
     pv = prof[dom]
@@ -308,11 +327,16 @@ def main():
     if os.path.exists(pmc_path):
         # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/pmc_summary.py);
         # gfx950 correction: FETCH_SIZE counts half the bytes of a 16-B-per-lane stream (MI355X_MICROARCH.md, HBM)
-        pmc = json.load(open(pmc_path)).get(hbm_families.get(dom, ""), None)
-        if pmc:
-            traffic = (2.0 * pmc["fetch_kb_per_launch"] + pmc["write_kb_per_launch"]) * 1024.0
+        pmc_all = json.load(open(pmc_path))
+        want = hbm_families.get(dom, [])
+        hits = [v for k, v in pmc_all.items() if want and all(w in k for w in want)]
+        if hits:
+            n = sum(h["launches"] for h in hits)
+            traffic = sum((2.0 * h["fetch_kb_per_launch"] + h["write_kb_per_launch"]) * h["launches"] for h in hits) / max(n, 1) * 1024.0
     roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic, "avg_launch_ms": pv["ms"] / max(pv["launches"], 1), "alg_bytes_per_launch": pv["bytes"] / max(pv["launches"], 1),
+                "launches_per_step": pv["launches"] // nprof, "measured": "standalone launches (worker streams off) after the timed region; rocprofv3 of `bench.py --serial` agrees",
+                "concurrent_avg_launch_ms": (prof_conc[dom]["ms"] / max(prof_conc[dom]["launches"], 1)) if dom in prof_conc else None,
                 "note": "this family is classified HBM-streaming (96*S bytes binary / 192*S ip+hadamard per table) but measures integer-VALU bound: "
                         ">= 7 Fr Montgomery products (136 MACs each) per 96 B; see valu_roofline"}
     # integer-VALU view of the same kernel and of the G1 (MSM) kernels: 32x32->64 MACs per second against the

@@ -370,12 +370,18 @@ __global__ void __launch_bounds__(64) k_msm_weighted(const MsmJob* __restrict__ 
   const uint32_t j = lane >> 2, t = lane & 3u;
   const G1J* rc = RC + (uint64_t)q * sh.nsums;
   G1J acc = g1_zero();
+  // the m-th index with bit i set is  ((m >> i) << (i + 1)) | 1 << i | (m & (2^i - 1)):  every iteration adds
   if (j < sh.LB) {  // column weights: bit j of lo
-    for (uint32_t lo = t; lo < sh.nlo; lo += 4)
-      if ((lo >> j) & 1u) acc = g1_add(acc, rc[sh.nhi + lo]);
-  } else if (j < c) {  // row weights: bit j - LB of hi
-    for (uint32_t hi = t; hi < sh.nhi; hi += 4)
-      if ((hi >> (j - sh.LB)) & 1u) acc = g1_add(acc, rc[hi]);
+    for (uint32_t m = t; m < sh.nlo / 2; m += 4) {
+      uint32_t lo = ((m >> j) << (j + 1)) | (1u << j) | (m & ((1u << j) - 1u));
+      acc = g1_add(acc, rc[sh.nhi + lo]);
+    }
+  } else if (j < c) {  // row weights: bit j - LB of hi (hi <= nhi - 1, a power of two)
+    const uint32_t i = j - sh.LB;
+    for (uint32_t m = t; m < sh.nhi - 1; m += 4) {
+      uint32_t hi = ((m >> i) << (i + 1)) | (1u << i) | (m & ((1u << i) - 1u));
+      if (hi < sh.nhi) acc = g1_add(acc, rc[hi]);
+    }
   }
   acc = g1_add(acc, g1_shfl_xor(acc, 1));
   acc = g1_add(acc, g1_shfl_xor(acc, 2));
