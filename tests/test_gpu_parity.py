@@ -483,3 +483,43 @@ def test_sealed_transcripts_pipeline_proofs_without_changing_them(zk, oracle):
     fr, _ = trs[0].read()
     zk.set_flag("lanes", 1)
     assert eq(fr, want[0][0])
+
+
+def test_recorded_batched_layers_equal_immediate_execution(zk, oracle):
+    """zk_fc_prove / zk_relu_prove only RECORD their launches; the flush zips the same kernel of different
+    layers into one launch (blockIdx.z = job) and spreads independent pieces over streams.  Pure scheduling:
+    the transcript must equal the one produced with batching off (every launch enqueued immediately), also
+    when other entry points are called between the prove calls (they settle the recorded work first)."""
+    from mlp_util import enqueue_proof, setup_mlp_gpu, synth_mlp
+    from zkdl_amd.capi import MSM_PIPPENGER, Transcript
+    zk.set_msm_mode(MSM_PIPPENGER)
+    model = synth_mlp(oracle, [24, 40, 16, 56, 8], 6, seed=77)   # ragged widths: chains of different lengths
+    st = setup_mlp_gpu(zk, model)
+    runs = {}
+    for batch, lanes in ((0, 0), (1, 0), (1, 1), (0, 1)):
+        zk.set_flag("batch_layers", batch)
+        zk.set_flag("lanes", lanes)
+        tr = Transcript(zk)
+        enqueue_proof(st, model["chal"], tr)
+        fr, _ = tr.read()
+        aff, inf = tr.read_affine()
+        runs[(batch, lanes)] = (fr, aff, inf)
+    zk.set_flag("batch_layers", 1)
+    zk.set_flag("lanes", 1)
+    ref = runs[(0, 0)]
+    for key, r in runs.items():
+        assert eq(r[0], ref[0]) and eq(r[1], ref[1]) and eq(r[2], ref[2]), key
+    # interleave unrelated entry points between the prove calls
+    tr = Transcript(zk)
+    scratch = zk.fr_random(100)
+    L = st["L"]
+    for kind, i, ch in model["chal"]:
+        if kind == "fc":
+            x_in = st["A"][i - 1] if i > 0 else st["X"]
+            z_out = st["Yhat"] if i == L - 1 else st["Z"][i]
+            st["fcs"][i].prove(x_in, z_out, st["gens"][i], ch[0], ch[1], ch[2], tr)
+        else:
+            st["relus"][i].prove(st["Z"][i], st["A"][i], ch, tr)
+        scratch = zk.fr_add(scratch, scratch)            # settles what has been recorded so far
+    fr, _ = tr.read()
+    assert eq(fr, ref[0])

@@ -1,10 +1,8 @@
-run() { timeout -k 10 120 python bench.py --steps 16 --warmup 3 --no-cpu-baseline $2 > gpurun_out/sw.log 2>&1 || { echo "$1 FAILED/timeout"; tail -3 gpurun_out/sw.log; return 0; }
+run() { timeout -k 10 120 python bench.py --steps 20 --warmup 3 --no-cpu-baseline $2 > gpurun_out/sw.log 2>&1 || { echo "$1 FAILED/timeout"; tail -3 gpurun_out/sw.log; return 0; }
 python3 -c "
 import json,sys
 d=json.loads(open('gpurun_out/sw.log').read().strip().split('\n')[-1])
 k=d['kernels']
 print(sys.argv[1], round(d['ms_per_step'],2), round(d['host_enqueue_ms_per_step'],2), d['aggregate_fr'][:14], {n[4:]:round(k[n]['ms_per_step'],2) for n in k if n.startswith('msm_') or n.startswith('g1_c')})
 " "$1"; }
-run "pipelined" ""
-ZKDL_G1_STREAMS=2 run "g1s=2" ""
-run "nopipe" "--no-pipeline"
+for c in 10 11 12 13 9; do run "c=$c" "--msm-window $c"; done
