@@ -25,7 +25,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 MLP18M = [784, 1000, 1773, 1773, 1773, 1773, 1773, 1124, 1000]      # model.py:14-30
-WORKLOADS = {"mlp18m_b256": (MLP18M, 256), "mlp18m_b1": (MLP18M, 1), "tiny": ([64, 96, 48, 32], 16)}
+WORKLOADS = {"mlp18m_b256": (MLP18M, 256), "mlp18m_b1": (MLP18M, 1), "tiny": ([64, 96, 48, 32], 16),
+             "deep4096x64_b256": ([4096] * 65, 256), "deep4096x8_b256": ([4096] * 9, 256)}   # BASELINE configs[4] (a parity/stress case, not the bench line)
 R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
