@@ -523,3 +523,26 @@ def test_recorded_batched_layers_equal_immediate_execution(zk, oracle):
         scratch = zk.fr_add(scratch, scratch)            # settles what has been recorded so far
     fr, _ = tr.read()
     assert eq(fr, ref[0])
+
+
+def test_int16_weight_contractions_equal_the_fr_path(zk, oracle):
+    """Quantised layers keep an int16 copy of W; the prover's two contractions of W (partial_me(u_out, 1) and
+    the row fold of Commitment::open) then run as 8x1-limb products accumulated unreduced.  Same field
+    elements: the transcript must not depend on the flag, and must still equal the oracle's."""
+    from mlp_util import enqueue_proof, prove_mlp_oracle, setup_mlp_gpu, synth_mlp
+    from zkdl_amd.capi import MSM_PIPPENGER, Transcript
+    zk.set_msm_mode(MSM_PIPPENGER)
+    model = synth_mlp(oracle, [48, 96, 40, 24], 5, seed=91)
+    out = {}
+    for flag in (1, 0):
+        zk.set_flag("weights_q16", flag)
+        st = setup_mlp_gpu(zk, model)
+        tr = Transcript(zk)
+        enqueue_proof(st, model["chal"], tr)
+        fr, _ = tr.read()
+        aff, inf = tr.read_affine()
+        out[flag] = (fr, aff, inf)
+    zk.set_flag("weights_q16", 1)
+    assert eq(out[1][0], out[0][0]) and eq(out[1][1], out[0][1]) and eq(out[1][2], out[0][2])
+    want_fr = prove_mlp_oracle(oracle, model)[0]
+    assert eq(out[1][0], want_fr)

@@ -1,9 +1,9 @@
-run() { timeout -k 10 120 python bench.py --steps 20 --warmup 3 --no-cpu-baseline $2 > gpurun_out/sw.log 2>&1 || { echo "$1 FAILED/timeout"; tail -3 gpurun_out/sw.log; return 0; }
+run() { timeout -k 10 300 python bench.py --steps $3 --warmup 3 --no-cpu-baseline $2 > gpurun_out/sw.log 2>&1 || { echo "$1 FAILED/timeout"; tail -3 gpurun_out/sw.log; return 0; }
 python3 -c "
 import json,sys
 d=json.loads(open('gpurun_out/sw.log').read().strip().split('\n')[-1])
 k=d['kernels']
-print(sys.argv[1], round(d['ms_per_step'],2), round(d['host_enqueue_ms_per_step'],2), d['aggregate_fr'][:14], {n:round(k[n]['ms_per_step'],2) for n in list(k)[:9]})
+print(sys.argv[1], round(d['ms_per_step'],2), round(d['host_enqueue_ms_per_step'],2), d['aggregate_fr'][:14], {n:(round(k[n]['ms_per_step'],2), round(k[n]['alg_GBps'])) for n in list(k)[:9]})
 " "$1"; }
-run "pipelined" ""
-run "pipelined" ""
+run "18m" "" 20
+run "deep64" "--workload deep4096x64_b256" 6

@@ -541,6 +541,7 @@ int zk_set_flag(zk_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "relu_packed")) ctx->relu_packed = value != 0;
   else if (!strcmp(name, "lanes")) ctx->lanes_enabled = value != 0;
   else if (!strcmp(name, "batch_layers")) ctx->batch_layers = value != 0;
+  else if (!strcmp(name, "weights_q16")) ctx->flag_q16 = value != 0;
   else return ctx->fail(ZK_ERR_ARG, std::string("unknown flag: ") + name);
   return ZK_OK;
 }
@@ -647,6 +648,7 @@ int zk_fc_destroy(zk_fc* fc) {
     fc->ctx->join_all();
   }
   if (fc->ctx) dev_free(fc->ctx, fc->weights);
+  if (fc->ctx) dev_free(fc->ctx, fc->wq);
   gens_destroy(fc->com);
   delete fc;
   return ZK_OK;

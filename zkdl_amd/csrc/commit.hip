@@ -127,7 +127,8 @@ int me_open_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32_t k,
 }
 
 // Commitment::open, commitment.cu:83-92.  u = u_lo || u_hi with |u_hi| = ceilLog2(m).
-int open_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, uint32_t tn, zk_gens* com, const Fr* u_d, uint32_t k, G1J* com_eval_d, G1J* proof_d, Fr* ret_d, MsmQueue* queue) {
+int open_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, uint32_t tn, zk_gens* com, const Fr* u_d, uint32_t k, G1J* com_eval_d, G1J* proof_d, Fr* ret_d, MsmQueue* queue,
+             const int16_t* tq) {
   const uint32_t n = g->n, m = com->n;
   uint32_t k_hi = ceil_log2(m);
   if (k_hi > k) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
@@ -142,7 +143,8 @@ int open_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, uint32_t tn, zk_gens* com, co
   uint32_t fsz = fr_partial_me_size(tn, k_hi, n);
   if (fsz != n) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   ZK_ALLOC(ctx, folded, Fr, n);
-  ZK_TRY(fr_partial_me_dev(ctx, t, tn, u_hi, k_hi, n, folded.get()));
+  if (tq && k_hi > 0) ZK_TRY(fr_partial_me_q16_dev(ctx, tq, tn, u_hi, k_hi, n, folded.get()));
+  else ZK_TRY(fr_partial_me_dev(ctx, t, tn, u_hi, k_hi, n, folded.get()));
   return me_open_dev(ctx, g, folded.get(), u_lo, k_lo, proof_d, ret_d, queue);
 }
 

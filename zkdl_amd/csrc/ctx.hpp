@@ -41,6 +41,7 @@ struct zk_ctx {
   // MSM configuration
   int msm_mode = ZK_MSM_PIPPENGER;
   uint32_t msm_window = 0;
+  bool flag_q16 = true;     // keep an int16 copy of quantised weights for the prover's contractions of W
   bool relu_packed = true;  // ReLU aux proofs from packed bits (relu_packed.hip) instead of one-Fr-per-bit tensors
   // timing
   hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -374,6 +375,8 @@ int fr_unary(zk_ctx* ctx, int op, const Fr* a, Fr* out, uint32_t n);
 int fr_sum_dev(zk_ctx* ctx, const Fr* a, uint32_t n, Fr* dst_d);
 int fr_me_dev(zk_ctx* ctx, const Fr* t, uint32_t n, const Fr* u_d, uint32_t k, Fr* dst_d);
 int fr_partial_me_dev(zk_ctx* ctx, const Fr* t, uint32_t n, const Fr* u_d, uint32_t k, uint32_t window, Fr* out_d);
+int fr_partial_me_q16_dev(zk_ctx* ctx, const int16_t* q, uint32_t n, const Fr* u_d, uint32_t k, uint32_t window, Fr* out_d);
+int fr_quant16_dev(zk_ctx* ctx, const Fr* t, uint32_t n, int16_t* q, uint32_t* overflow_d);
 int fr_fold_dev(zk_ctx* ctx, const Fr* in, Fr* out, const Fr* x_d, uint32_t in_size, uint32_t out_size);
 uint32_t fr_partial_me_size(uint32_t n, uint32_t k, uint32_t window);
 int fr_split_dev(zk_ctx* ctx, const Fr* t, uint32_t n, uint32_t window, Fr* o0, Fr* o1);

@@ -114,31 +114,45 @@ __device__ __forceinline__ void k_eq_table(uint32_t zk_nblk, const Fr* __restric
 }
 
 // out[h*W + w] = sum_{m<M} E[m] * t[(h*M + m)*W + w]   (zero beyond n); one thread per output.
+// HBM-streaming: the row loop is unrolled so that several 32-byte loads per lane are in flight.
 __device__ __forceinline__ void k_colsum(uint32_t zk_nblk, const Fr* __restrict__ t, uint32_t n, const Fr* __restrict__ E, uint32_t M, uint32_t W,
                                                  uint32_t total_out, Fr* __restrict__ out) {
   for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total_out; idx += zk_nblk * blockDim.x) {
     uint32_t h = idx / W, w = idx - h * W;
     Fr acc = fr_zero();
     uint64_t base = (uint64_t)h * M * W + w;
-    for (uint32_t m = 0; m < M; m++) {
+    uint32_t m = 0;
+    for (; m + 4 <= M && base + (uint64_t)(m + 3) * W < n; m += 4) {
+      Fr v0 = t[base + (uint64_t)m * W], v1 = t[base + (uint64_t)(m + 1) * W], v2 = t[base + (uint64_t)(m + 2) * W], v3 = t[base + (uint64_t)(m + 3) * W];
+      acc = fr_add(acc, fr_add(fr_add(fr_mul(E[m], v0), fr_mul(E[m + 1], v1)), fr_add(fr_mul(E[m + 2], v2), fr_mul(E[m + 3], v3))));
+    }
+    for (; m < M; m++) {
       uint64_t src = base + (uint64_t)m * W;
       if (src < n) acc = fr_add(acc, fr_mul(E[m], t[src]));
     }
     out[idx] = acc;
   }
 }
-// W == 1, M >= 64: one block per output h, lanes stride the contiguous row.
-__device__ __forceinline__ void k_dot_block(uint32_t zk_nblk, const Fr* __restrict__ t, uint32_t n, const Fr* __restrict__ E, uint32_t M, Fr* __restrict__ out) {
-  __shared__ Fr lds[4];
-  uint32_t h = blockIdx.x;
+// W == 1, M >= 64: one WAVE per output h (four per workgroup); lanes stride the contiguous row, four loads in
+// flight, and the only reduction is the wave's shuffle ladder (no LDS stage, no barriers).
+__device__ __forceinline__ void k_dot_block(uint32_t zk_nblk, const Fr* __restrict__ t, uint32_t n, const Fr* __restrict__ E, uint32_t M, Fr* __restrict__ out,
+                                                    uint32_t H) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t h = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (h >= H) return;
   uint64_t base = (uint64_t)h * M;
   Fr acc = fr_zero();
-  for (uint32_t m = threadIdx.x; m < M; m += blockDim.x) {
+  uint32_t m = lane;
+  for (; m + 192 < M && base + m + 192 < n; m += 256) {
+    Fr v0 = t[base + m], v1 = t[base + m + 64], v2 = t[base + m + 128], v3 = t[base + m + 192];
+    acc = fr_add(acc, fr_add(fr_add(fr_mul(E[m], v0), fr_mul(E[m + 64], v1)), fr_add(fr_mul(E[m + 128], v2), fr_mul(E[m + 192], v3))));
+  }
+  for (; m < M; m += 64) {
     uint64_t src = base + m;
     if (src < n) acc = fr_add(acc, fr_mul(E[m], t[src]));
   }
-  acc = block_sum_fr(acc, lds);
-  if (threadIdx.x == 0) out[h] = acc;
+  acc = wave_sum_fr(acc);
+  if (lane == 0) out[h] = acc;
 }
 
 static int eq_table(zk_ctx* ctx, const Fr* u_d, uint32_t c, Fr* E) {
@@ -154,12 +168,155 @@ static int contract(zk_ctx* ctx, const Fr* t, uint32_t n, const Fr* u_d, uint32_
   ZK_TRY(eq_table(ctx, u_d, c, E.get()));
   uint64_t bytes = 32ull * ((uint64_t)n + (uint64_t)H * W);
   if (W == 1 && M >= 64) {
-    ZK_LAUNCHB(ctx, "fr_contract", bytes, 256, k_dot_block, dim3(H), 0, t, n, (const Fr*)E.get(), M, out);
+    ZK_LAUNCHB(ctx, "fr_contract", bytes, 256, k_dot_block, dim3((H + 3) / 4), 0, t, n, (const Fr*)E.get(), M, out, H);
   } else {
     uint32_t total = H * W;
     ZK_LAUNCHB(ctx, "fr_contract", bytes, 256, k_colsum, dim3(stream_grid(total)), 0, t, n, (const Fr*)E.get(), M, W, total, out);
   }
   return ZK_OK;
+}
+
+// ------------------------------------------------------------------ contractions of a QUANTISED tensor
+// A layer's weights are small signed integers (|w| < 2^15 after zkfc.cu:80-88's scaling); the prover reads
+// them twice per proof (W.partial_me(u_out, 1) and the row fold of Commitment::open), and a full Montgomery
+// product per 32-byte element caps that at ~3.3 TB/s of issue rate.  With the weights also kept as int16,
+// E[m] * w is an 8-limb x 1-limb product accumulated UNREDUCED in 9 limbs (sum of <= 2^11 terms < 2^283), and
+// only each output is reduced mod r: ~40 instructions and 2 bytes per element instead of ~330 and 32.
+// The value is the same field element: sum_m E[m] * w_m mod r with E in Montgomery form, i.e. exactly what
+// Fr_partial_me computes on the Montgomery-form weights.
+struct Acc9 {
+  uint32_t v[9];
+};
+__device__ __forceinline__ Acc9 acc9_zero() {
+  Acc9 a;
+#pragma unroll
+  for (int i = 0; i < 9; i++) a.v[i] = 0;
+  return a;
+}
+// a += (q < 0 ? r - e : e) * |q|
+__device__ __forceinline__ void acc9_mac(Acc9& a, const Fr& e, int32_t q) {
+  const uint32_t mag = (uint32_t)(q < 0 ? -q : q);
+  const Fr x = q < 0 ? fr_neg(e) : e;
+  uint64_t carry = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t t = (uint64_t)x.v[i] * mag + a.v[i] + carry;
+    a.v[i] = (uint32_t)t;
+    carry = t >> 32;
+  }
+  a.v[8] += (uint32_t)carry;
+}
+__device__ __forceinline__ Acc9 acc9_add(const Acc9& a, const Acc9& b) {
+  Acc9 r;
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    uint32_t co;
+    r.v[i] = __builtin_addc(a.v[i], b.v[i], c, &co);
+    c = co;
+  }
+  return r;
+}
+// T = lo + hi * 2^256  ->  T mod r:  lo < 2^256 < 5r by repeated subtraction, hi * 2^256 = mont(hi)
+__device__ __forceinline__ Fr acc9_reduce(const Acc9& a) {
+  Fr lo;
+#pragma unroll
+  for (int i = 0; i < 8; i++) lo.v[i] = a.v[i];
+#pragma unroll
+  for (int it = 0; it < 4; it++) lo = f_reduce_once<FrP>(lo);
+  Fr hi = fr_zero();
+  hi.v[0] = a.v[8];
+  return fr_add(lo, fr_mont(hi));
+}
+__device__ __forceinline__ Acc9 wave_sum_acc9(Acc9 x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    Acc9 y;
+#pragma unroll
+    for (int i = 0; i < 9; i++) y.v[i] = __shfl_down(x.v[i], off, 64);
+    x = acc9_add(x, y);
+  }
+  return x;
+}
+// out[h*W + w] = sum_{m<M} E[m] * q[(h*M + m)*W + w]; one thread per output
+__device__ __forceinline__ void k_colsum_q16(uint32_t zk_nblk, const int16_t* __restrict__ q, uint32_t n, const Fr* __restrict__ E, uint32_t M, uint32_t W,
+                                                     uint32_t total_out, Fr* __restrict__ out) {
+  for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total_out; idx += zk_nblk * blockDim.x) {
+    uint32_t h = idx / W, w = idx - h * W;
+    Acc9 acc = acc9_zero();
+    uint64_t base = (uint64_t)h * M * W + w;
+    for (uint32_t m = 0; m < M; m++) {
+      uint64_t src = base + (uint64_t)m * W;
+      if (src < n) acc9_mac(acc, E[m], q[src]);
+    }
+    out[idx] = acc9_reduce(acc);
+  }
+}
+// W == 1: one wave per output h, lanes stride the contiguous row
+__device__ __forceinline__ void k_dot_q16(uint32_t zk_nblk, const int16_t* __restrict__ q, uint32_t n, const Fr* __restrict__ E, uint32_t M, Fr* __restrict__ out,
+                                                  uint32_t H) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t h = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (h >= H) return;
+  uint64_t base = (uint64_t)h * M;
+  Acc9 acc = acc9_zero();
+  for (uint32_t m = lane; m < M; m += 64) {
+    uint64_t src = base + m;
+    if (src < n) acc9_mac(acc, E[m], q[src]);
+  }
+  acc = wave_sum_acc9(acc);
+  if (lane == 0) out[h] = acc9_reduce(acc);
+}
+// w (Montgomery) -> int16 if |w| < 2^15, else *overflow is set
+__device__ __forceinline__ void k_quant16(uint32_t zk_nblk, const Fr* __restrict__ t, uint32_t n, int16_t* __restrict__ q, uint32_t* __restrict__ overflow) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += zk_nblk * blockDim.x) {
+    Fr v = fr_unmont(t[i]);
+    Fr nv = fr_neg(v);
+    uint32_t hi_v = 0, hi_n = 0;
+#pragma unroll
+    for (int l = 1; l < 8; l++) {
+      hi_v |= v.v[l];
+      hi_n |= nv.v[l];
+    }
+    int32_t r = 0;
+    if (hi_v == 0 && v.v[0] < 32768u) r = (int32_t)v.v[0];
+    else if (hi_n == 0 && nv.v[0] <= 32768u) r = -(int32_t)nv.v[0];
+    else atomicOr(overflow, 1u);
+    q[i] = (int16_t)r;
+  }
+}
+int fr_quant16_dev(zk_ctx* ctx, const Fr* t, uint32_t n, int16_t* q, uint32_t* overflow_d) {
+  ZK_LAUNCHB(ctx, "fr_quant16", 34ull * n, 256, k_quant16, dim3(stream_grid(n)), 0, t, n, q, overflow_d);
+  return ZK_OK;
+}
+
+// FrTensor::partial_me over the int16 copy of a quantised tensor: the first level (all the traffic) reads the
+// int16s, the remaining levels fold its Fr output exactly as fr_partial_me_dev does
+int fr_partial_me_q16_dev(zk_ctx* ctx, const int16_t* q, uint32_t n, const Fr* u_d, uint32_t k, uint32_t W, Fr* out_d) {
+  if (W == 0 || k == 0 || k > 31) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
+  if ((uint64_t)n <= (uint64_t)W * (1ull << (k - 1))) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
+  const uint32_t nw = (uint32_t)(((uint64_t)n + W - 1) / W);
+  const uint32_t cmax = (W == 1) ? 10 : 6;
+  const uint32_t c = k < cmax ? k : cmax;
+  const uint32_t M = 1u << c;
+  const uint32_t H = (nw + M - 1) / M;
+  DBuf<Fr> tmp;
+  Fr* out = out_d;
+  if (k != c) {
+    if (!tmp.alloc(ctx, (size_t)H * W)) return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: partial_me temp");
+    out = tmp.get();
+  }
+  ZK_ALLOC(ctx, E, Fr, M);
+  ZK_TRY(eq_table(ctx, u_d, c, E.get()));
+  const uint64_t bytes = 2ull * n + 32ull * ((uint64_t)H * W + M);
+  if (W == 1 && M >= 64) {
+    ZK_LAUNCHB(ctx, "fr_contract_q16", bytes, 256, k_dot_q16, dim3((H + 3) / 4), 0, q, n, (const Fr*)E.get(), M, out, H);
+  } else {
+    uint32_t total = H * W;
+    ZK_LAUNCHB(ctx, "fr_contract_q16", bytes, 256, k_colsum_q16, dim3(stream_grid(total)), 0, q, n, (const Fr*)E.get(), M, W, total, out);
+  }
+  if (k == c) return ZK_OK;
+  return fr_partial_me_dev(ctx, out, H * W, u_d + c, k - c, W, out_d);
 }
 
 // FrTensor::operator()(u) (fr-tensor.cu:295-300 guard, :411-418 semantics); result to dst_d

@@ -255,6 +255,19 @@ int fc_create(zk_ctx* ctx, uint32_t in, uint32_t out, const Fr* weights_d, zk_ge
     zk_fc_destroy(fc);
     return rc;
   }
+  // int16 copy for the prover's two contractions of W (setup time: one host round trip for the range flag)
+  if (ctx->flag_q16 && dev_alloc(ctx, (void**)&fc->wq, wn * sizeof(int16_t)) == hipSuccess) {
+    ZK_ALLOC(ctx, ovf, uint32_t, 1);
+    uint32_t h_ovf = 1;
+    rc = dev_zero(ctx, ovf.get(), 4);
+    if (rc == ZK_OK) rc = fr_quant16_dev(ctx, fc->weights, (uint32_t)wn, fc->wq, ovf.get());
+    if (rc == ZK_OK) rc = dev_to_host(ctx, &h_ovf, ovf.get(), 4);
+    if (rc != ZK_OK || h_ovf) {  // not a quantised layer: the Fr path serves it
+      dev_free(ctx, fc->wq);
+      fc->wq = nullptr;
+    }
+    (void)hipGetLastError();
+  }
   *out_fc = fc;
   return ZK_OK;
 }
@@ -315,14 +328,15 @@ int fc_prove(zk_ctx* ctx, zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint
   ZK_ALLOC(ctx, b, Fr, bsz);
   // three independent pieces (recorded as separate chains): the inner-product sumcheck, Z(u_Z), the opening
   ZK_TRY(fr_partial_me_dev(ctx, x, xn, u_bs, k_bs, fc->in, a.get()));
-  ZK_TRY(fr_partial_me_dev(ctx, fc->weights, wn, u_out, k_out, 1, b.get()));
+  if (fc->wq && k_out > 0) ZK_TRY(fr_partial_me_q16_dev(ctx, fc->wq, wn, u_out, k_out, 1, b.get()));
+  else ZK_TRY(fr_partial_me_dev(ctx, fc->weights, wn, u_out, k_out, 1, b.get()));
   ZK_TRY(sumcheck_ip_dev(ctx, a.get(), b.get(), asz, u_in, k_in, fr_slot));
   // Z(u_Z)
   rec_split(ctx, REC_GROUP_FC_A);
   ZK_TRY(fr_me_dev(ctx, z, zn, uz.get(), k_out + k_bs, fr_slot + 3 * k_in + 2));
   // generators.open(weights, com, u_out || u_in)
   rec_split(ctx, REC_GROUP_FC_OPEN);
-  ZK_TRY(open_dev(ctx, gens, fc->weights, wn, fc->com, u_out, k_out + k_in, g1_slot, g1_slot + 1, fr_slot + 3 * k_in + 3, &tr->queue));
+  ZK_TRY(open_dev(ctx, gens, fc->weights, wn, fc->com, u_out, k_out + k_in, g1_slot, g1_slot + 1, fr_slot + 3 * k_in + 3, &tr->queue, fc->wq));
   return ZK_OK;
 }
 

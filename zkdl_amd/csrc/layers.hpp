@@ -35,6 +35,7 @@ struct zk_fc {  // zkFC, zkfc.cuh:16-33: padded weights (Montgomery, [in][out]) 
   zk_ctx* ctx = nullptr;
   uint32_t in = 0, out = 0, m = 0, n_gens = 0;
   zk::Fr* weights = nullptr;
+  int16_t* wq = nullptr;   // the same weights as int16 when every |w| < 2^15 (quantised layers), else nullptr
   zk_gens* com = nullptr;  // the m commitment points, wrapped so com(u) can run as a table MSM
   uint32_t serial = 0;     // lane hint
 };
@@ -90,7 +91,8 @@ int g1_canonicalise_dev(zk_ctx* ctx, G1J* pts, uint32_t n);
 int commit_dev(zk_ctx* ctx, zk_gens* gens, const Fr* t, uint32_t tn, G1J* out);
 // queue == nullptr: run now; otherwise (PIPPENGER back end) the MSMs are deferred to msm_flush(queue)
 int me_open_dev(zk_ctx* ctx, zk_gens* gens, const Fr* t, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d, MsmQueue* queue);
-int open_dev(zk_ctx* ctx, zk_gens* gens, const Fr* t, uint32_t tn, zk_gens* com, const Fr* u_d, uint32_t k, G1J* com_eval_d, G1J* proof_d, Fr* ret_d, MsmQueue* queue);
+int open_dev(zk_ctx* ctx, zk_gens* gens, const Fr* t, uint32_t tn, zk_gens* com, const Fr* u_d, uint32_t k, G1J* com_eval_d, G1J* proof_d, Fr* ret_d, MsmQueue* queue,
+             const int16_t* tq = nullptr);  // tq: optional int16 copy of t (quantised weights)
 int fc_create(zk_ctx* ctx, uint32_t in, uint32_t out, const Fr* weights_d, zk_gens* gens, zk_fc** out_fc);
 int fc_forward(zk_ctx* ctx, const zk_fc* fc, const Fr* x, uint32_t xn, Fr* z);
 int fc_prove(zk_ctx* ctx, zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint32_t zn, zk_gens* gens,
