@@ -351,7 +351,7 @@ def test_open_and_msm_batch_pippenger(zk, oracle, rng):
         assert bm.jac_to_affine_int(out[row]) == want
 
 
-@pytest.mark.parametrize("window", [0, 4, 9])
+@pytest.mark.parametrize("window", [0, 4, 9, 11, 12])
 def test_msm_window_sweep_gives_same_points(zk, oracle, rng, window):
     from zkdl_amd.capi import MSM_PIPPENGER
     zk.set_msm_mode(MSM_PIPPENGER)

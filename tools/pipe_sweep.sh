@@ -3,7 +3,6 @@ python3 -c "
 import json,sys
 d=json.loads(open('gpurun_out/sw.log').read().strip().split('\n')[-1])
 k=d['kernels']
-print(sys.argv[1], round(d['ms_per_step'],2), round(d['host_enqueue_ms_per_step'],2), d['aggregate_fr'][:14], {n:(round(k[n]['ms_per_step'],2), round(k[n]['alg_GBps'])) for n in list(k)[:9]})
+print(sys.argv[1], round(d['ms_per_step'],2), d['aggregate_fr'][:14], {n[4:]:round(k[n]['ms_per_step'],2) for n in k if n.startswith('msm_') or n.startswith('g1_c')})
 " "$1"; }
-run "18m" "" 20
-run "deep64" "--workload deep4096x64_b256" 6
+for c in 10 11 12 9 8 7; do run "c=$c" "--msm-window $c" 20; done

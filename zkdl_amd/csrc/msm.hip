@@ -288,36 +288,6 @@ __global__ void __launch_bounds__(64) k_msm_accum(const MsmJob* __restrict__ job
   else tail[job.chunk_off + t] = acc;                        // starts inside, continues into the next chunk
 }
 
-// one lane per (job, bucket): empty -> infinity; split across chunks -> sum of the chunk partials
-__global__ void __launch_bounds__(64) k_msm_combine(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ off, G1J* __restrict__ buckets,
-                                                     const G1J* __restrict__ head, const G1J* __restrict__ tail) {
-  const uint32_t B = 1u << (c - 1);
-  const uint32_t q = blockIdx.y;
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x + 1;
-  if (b > B) return;
-  const MsmJob job = jobs[q];
-  const uint32_t* o = off + (uint64_t)q * (B + 2);
-  const uint32_t base = o[1], s = o[b], e = o[b + 1];
-  G1J* dst = buckets + (uint64_t)q * B + (b - 1);
-  if (s == e) {
-    *dst = g1_zero();
-    return;
-  }
-  const uint32_t t0 = (s - base) / MSM_CHUNK, t1 = (e - 1 - base) / MSM_CHUNK;
-  if (t0 == t1) return;  // complete inside one chunk: already stored by k_msm_accum
-  // chunk t0 holds the bucket's first piece: a tail unless the bucket starts exactly at the chunk start
-  G1J acc = ((s - base) == t0 * MSM_CHUNK) ? head[job.chunk_off + t0] : tail[job.chunk_off + t0];
-  for (uint32_t t = t0 + 1; t <= t1; t++) acc = g1_add(acc, head[job.chunk_off + t]);
-  *dst = acc;
-}
-
-// ---- bucket reduction  out[q] = sum_{b=1..B} b * S_b  without a running-sum chain and without idle lanes.
-// Write b = hi * 2^LB + lo.  Then  sum_b b*S_b = sum_lo lo*C_lo + 2^LB * sum_hi hi*R_hi  with the row sums
-// R_hi = sum_lo S_b and column sums C_lo = sum_hi S_b: 2B additions instead of the (c/2)*B of summing one
-// bit-slice of the bucket index at a time over all buckets.  The two small weighted sums (2^LB and B/2^LB + 1
-// terms) are then taken bit-slice by bit-slice: T_j, j < c, and out = sum_j 2^j T_j.
-// Both kernels keep every lane busy with a short sequential run of additions and use few waves, so they
-// share the machine with the next proof's Fr work instead of parking thousands of barrier-bound waves on it.
 __device__ __forceinline__ G1J g1_shfl_xor(const G1J& p, int mask) {
   G1J r;
 #pragma unroll
@@ -328,6 +298,44 @@ __device__ __forceinline__ G1J g1_shfl_xor(const G1J& p, int mask) {
   }
   return r;
 }
+// four lanes per (job, bucket): empty -> infinity; split across chunks -> sum of the chunk partials, each lane
+// adding every fourth partial and two butterfly steps joining them.  (The top window of a scalar < r/2 has one
+// or two bits of entropy, so for some window widths half of all points of an MSM land in one bucket: a single
+// lane would walk ~100 additions there.)
+__global__ void __launch_bounds__(64) k_msm_combine(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ off, G1J* __restrict__ buckets,
+                                                     const G1J* __restrict__ head, const G1J* __restrict__ tail) {
+  const uint32_t B = 1u << (c - 1);
+  const uint32_t q = blockIdx.y;
+  const uint32_t sub = threadIdx.x & 3u;
+  const uint32_t b = blockIdx.x * 16u + (threadIdx.x >> 2) + 1;
+  const bool live = b <= B;
+  const MsmJob job = jobs[q];
+  const uint32_t* o = off + (uint64_t)q * (B + 2);
+  const uint32_t base = o[1];
+  const uint32_t s = live ? o[b] : 0, e = live ? o[b + 1] : 0;
+  G1J acc = g1_zero();
+  bool store = live && s == e;  // empty bucket: infinity
+  if (live && s != e) {
+    const uint32_t t0 = (s - base) / MSM_CHUNK, t1 = (e - 1 - base) / MSM_CHUNK;
+    if (t0 != t1) {  // (t0 == t1: complete inside one chunk, already stored by k_msm_accum)
+      store = true;
+      // chunk t0 holds the bucket's first piece: a tail unless the bucket starts exactly at the chunk start
+      if (sub == 0) acc = ((s - base) == t0 * MSM_CHUNK) ? head[job.chunk_off + t0] : tail[job.chunk_off + t0];
+      for (uint32_t t = t0 + 1 + sub; t <= t1; t += 4) acc = g1_add(acc, head[job.chunk_off + t]);
+    }
+  }
+  acc = g1_add(acc, g1_shfl_xor(acc, 1));
+  acc = g1_add(acc, g1_shfl_xor(acc, 2));
+  if (store && sub == 0) buckets[(uint64_t)q * B + (b - 1)] = acc;
+}
+
+// ---- bucket reduction  out[q] = sum_{b=1..B} b * S_b  without a running-sum chain and without idle lanes.
+// Write b = hi * 2^LB + lo.  Then  sum_b b*S_b = sum_lo lo*C_lo + 2^LB * sum_hi hi*R_hi  with the row sums
+// R_hi = sum_lo S_b and column sums C_lo = sum_hi S_b: 2B additions instead of the (c/2)*B of summing one
+// bit-slice of the bucket index at a time over all buckets.  The two small weighted sums (2^LB and B/2^LB + 1
+// terms) are then taken bit-slice by bit-slice: T_j, j < c, and out = sum_j 2^j T_j.
+// Both kernels keep every lane busy with a short sequential run of additions and use few waves, so they
+// share the machine with the next proof's Fr work instead of parking thousands of barrier-bound waves on it.
 struct ReduceShape {
   uint32_t LB, nlo, nhi, nsums;  // sums 0..nhi-1: rows, nhi..nhi+nlo-1: columns
 };
@@ -479,7 +487,7 @@ int msm_run_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs, uint32_t c) 
   ZK_LAUNCH(ctx, "msm_sort", 32ull * pairs + 4ull * items, k_msm_sort, dim3(nj), dim3(1024), lds, (const MsmJob*)djobs.get(), c, K, idx.get(), off.get());
   ZK_LAUNCH(ctx, "msm_accum", 100ull * items, k_msm_accum, dim3((max_chunks + 63) / 64, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, (const uint32_t*)idx.get(),
             (const uint32_t*)off.get(), buckets.get(), head.get(), tail.get());
-  ZK_LAUNCH(ctx, "msm_combine", 144ull * nj * B, k_msm_combine, dim3((B + 63) / 64, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, (const uint32_t*)off.get(), buckets.get(),
+  ZK_LAUNCH(ctx, "msm_combine", 144ull * nj * B, k_msm_combine, dim3((B + 15) / 16, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, (const uint32_t*)off.get(), buckets.get(),
             (const G1J*)head.get(), (const G1J*)tail.get());
   const ReduceShape sh = reduce_shape(c);
   ZK_LAUNCH(ctx, "msm_bucket_reduce", 144ull * nj * B, k_msm_rowcol, dim3((sh.nsums * 4 + 63) / 64, nj), dim3(64), 0, (const G1J*)buckets.get(), c, sh, RC.get());
