@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Host-side time of each prove call of the bench workload (no device wait inside the calls)."""
-import sys, time
+import os, sys, time
 sys.path.insert(0, ".")
 import torch  # noqa: F401  (loads the HIP runtime first, like bench.py)
 from zkdl_amd.capi import Zk
 import bench
 zk = Zk(0)
-dims, batch = bench.WORKLOADS["mlp18m_b256"]
+dims, batch = bench.WORKLOADS[os.environ.get("WORKLOAD", "mlp18m_b256")]
 wl = bench.Workload(zk, dims, batch, seed=0)
 L = len(wl.shapes)
 import os

@@ -7,7 +7,7 @@ import torch  # noqa: F401
 from zkdl_amd.capi import Zk
 import bench
 zk = Zk(0)
-dims, batch = bench.WORKLOADS["mlp18m_b256"]
+dims, batch = bench.WORKLOADS[os.environ.get("WORKLOAD", "mlp18m_b256")]
 wl = bench.Workload(zk, dims, batch, seed=0)
 for it in range(3):                      # warm pools
     wl.prove(wl.challenges(it)); wl.tr.flush(); zk.sync()
