@@ -700,8 +700,15 @@ int zk_relu_forward(zk_ctx* ctx, zk_relu* relu, const zk_fr* x, uint32_t n, zk_f
   return relu_forward(ctx, relu, F(x), n, F(z));
 }
 const zk_fr* zk_relu_sign(const zk_relu* r) { return r ? reinterpret_cast<const zk_fr*>(r->sign) : nullptr; }
-const zk_fr* zk_relu_mag_bin(const zk_relu* r) { return r ? reinterpret_cast<const zk_fr*>(r->mag_bin) : nullptr; }
-const zk_fr* zk_relu_rem_bin(const zk_relu* r) { return r ? reinterpret_cast<const zk_fr*>(r->rem_bin) : nullptr; }
+// the bit tensors are materialised (from the packed words) the first time they are asked for
+const zk_fr* zk_relu_mag_bin(const zk_relu* r) {
+  if (!r || !r->ctx || r->ctx->settle() != ZK_OK || relu_materialise_bins(r->ctx, const_cast<zk_relu*>(r)) != ZK_OK) return nullptr;
+  return reinterpret_cast<const zk_fr*>(r->mag_bin);
+}
+const zk_fr* zk_relu_rem_bin(const zk_relu* r) {
+  if (!r || !r->ctx || r->ctx->settle() != ZK_OK || relu_materialise_bins(r->ctx, const_cast<zk_relu*>(r)) != ZK_OK) return nullptr;
+  return reinterpret_cast<const zk_fr*>(r->rem_bin);
+}
 int zk_relu_prove(zk_ctx* ctx, const zk_relu* relu, const zk_fr* x, const zk_fr* z, uint32_t n, const zk_fr* u_z, const zk_fr* v_z, const zk_fr* u_r,
                   const zk_fr* v_r, const zk_fr* u_rec, const zk_fr* u_hp, const zk_fr* v_hp, zk_transcript* tr) {
   CHECK_CTX_NOJOIN(ctx);

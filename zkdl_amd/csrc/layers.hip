@@ -53,12 +53,89 @@ __global__ void __launch_bounds__(256) k_fr_matmul(const Fr* __restrict__ A, con
   if (row < rowsA && col < colsB) C[(uint64_t)row * colsB + col] = sum;
 }
 
+// ---- integer forward pass of a quantised layer.  Activations are small integers (|x| < 2^33: 16-bit-scaled
+// inputs, 32-bit rescaled ReLU outputs) and weights fit int16, so  Z = X W  is exact in int64
+// (2^33 * 2^15 * in <= 2^62 for in <= 2^14) and equals the field product the reference computes with one
+// Montgomery multiplication per term (zkfc.cu:6-47): ~5 instructions per term instead of ~350.
+__global__ void __launch_bounds__(256) k_fr_to_i64(const Fr* __restrict__ x, int64_t* __restrict__ out, uint32_t n, uint32_t* __restrict__ overflow) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    Fr v = fr_unmont(x[i]);
+    Fr nv = fr_neg(v);
+    uint32_t hv = 0, hn = 0;
+#pragma unroll
+    for (int l = 2; l < 8; l++) {
+      hv |= v.v[l];
+      hn |= nv.v[l];
+    }
+    int64_t r = 0;
+    if (hv == 0 && v.v[1] < 2u) r = (int64_t)(((uint64_t)v.v[1] << 32) | v.v[0]);
+    else if (hn == 0 && nv.v[1] < 2u) r = -(int64_t)(((uint64_t)nv.v[1] << 32) | nv.v[0]);
+    else atomicOr(overflow, 1u);
+    out[i] = r;
+  }
+}
+__global__ void __launch_bounds__(256) k_i64_to_fr(const int64_t* __restrict__ v, Fr* __restrict__ out, uint32_t n) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int64_t x = v[i];
+    const uint64_t mag = x < 0 ? (uint64_t)(-x) : (uint64_t)x;
+    Fr m = fr_zero();
+    m.v[0] = (uint32_t)mag;
+    m.v[1] = (uint32_t)(mag >> 32);
+    m = fr_mont(m);
+    out[i] = x < 0 ? fr_neg(m) : m;
+  }
+}
+// C[rowsA x colsB] = A[rowsA x colsA] (int64) * B[colsA x colsB] (int16); 64 x 64 tile per workgroup, 4 x 4 per lane
+#define ZK_GT 64
+#define ZK_GK 16
+__global__ void __launch_bounds__(256) k_gemm_i64_i16(const int64_t* __restrict__ A, const int16_t* __restrict__ B, int64_t* __restrict__ C, uint32_t rowsA, uint32_t colsA,
+                                                       uint32_t colsB) {
+  __shared__ int64_t At[ZK_GK][ZK_GT + 1];
+  __shared__ int32_t Bt[ZK_GK][ZK_GT];
+  const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
+  const uint32_t row0 = blockIdx.y * ZK_GT, col0 = blockIdx.x * ZK_GT;
+  int64_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = 0;
+  for (uint32_t k0 = 0; k0 < colsA; k0 += ZK_GK) {
+    for (uint32_t e = threadIdx.x; e < ZK_GT * ZK_GK; e += 256) {
+      uint32_t r = e / ZK_GK, k = e % ZK_GK;  // A tile: consecutive lanes walk k (contiguous in memory)
+      At[k][r] = (row0 + r < rowsA && k0 + k < colsA) ? A[(uint64_t)(row0 + r) * colsA + k0 + k] : 0;
+      uint32_t kb = e / ZK_GT, cb = e % ZK_GT;  // B tile: consecutive lanes walk the columns
+      Bt[kb][cb] = (k0 + kb < colsA && col0 + cb < colsB) ? (int32_t)B[(uint64_t)(k0 + kb) * colsB + col0 + cb] : 0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (uint32_t k = 0; k < ZK_GK; k++) {
+      int64_t a[4];
+      int64_t b[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) a[i] = At[k][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; j++) b[j] = (int64_t)Bt[k][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] += a[i] * b[j];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      uint32_t r = row0 + ty * 4 + i, cc = col0 + tx * 4 + j;
+      if (r < rowsA && cc < colsB) C[(uint64_t)r * colsB + cc] = acc[i][j];
+    }
+}
+
 // ------------------------------------------------------------------ ReLU (zkrelu.cu:3-41)
 // Writes the reference's aux tensors (one Fr per bit) AND the same bits packed (32 magnitude bits
 // per element in mag_packed, 16 remainder bits in rem_packed) for the bit-packed prover path.
-__global__ void __launch_bounds__(256) k_relu(const Fr* __restrict__ X, Fr* __restrict__ Z, Fr* __restrict__ sign, Fr* __restrict__ mag_bin, Fr* __restrict__ rem_bin,
-                                               uint32_t* __restrict__ mag_packed, uint16_t* __restrict__ rem_packed, uint8_t* __restrict__ sign_packed, uint32_t n,
-                                               uint32_t* __restrict__ out_of_range) {
+__global__ void __launch_bounds__(256) k_relu(const Fr* __restrict__ X, Fr* __restrict__ Z, Fr* __restrict__ sign, uint32_t* __restrict__ mag_packed,
+                                               uint16_t* __restrict__ rem_packed, uint8_t* __restrict__ sign_packed, uint32_t n, uint32_t* __restrict__ out_of_range) {
   const Fr one = fr_one(), zero = fr_zero();
   for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
     Fr x = fr_unmont(X[g]);
@@ -87,19 +164,22 @@ __global__ void __launch_bounds__(256) k_relu(const Fr* __restrict__ X, Fr* __re
     const int32_t rem = rem_sign ? ((int32_t)rem_mag - (1 << 15)) : (int32_t)rem_mag;
     const uint32_t mag_rescaled = (uint32_t)((mag - (uint64_t)(int64_t)rem) >> 16);
     sign[g] = positive ? one : zero;
-    Fr* mb = mag_bin + (uint64_t)g * 32;
-#pragma unroll 4
-    for (uint32_t i = 0; i < 32; i++) mb[i] = ((mag_rescaled >> i) & 1u) ? one : zero;
-    Fr* rb = rem_bin + (uint64_t)g * 16;
-#pragma unroll 4
-    for (uint32_t i = 0; i < 15; i++) rb[i] = ((rem_mag >> i) & 1u) ? one : zero;
-    rb[15] = rem_sign ? one : zero;
     mag_packed[g] = mag_rescaled;
     rem_packed[g] = (uint16_t)(rem_mag | (rem_sign ? 0x8000u : 0u));
     sign_packed[g] = positive ? 1 : 0;
     Fr mr = fr_zero();
     mr.v[0] = mag_rescaled;
     Z[g] = positive ? fr_mont(mr) : zero;  // mont(mag_rescaled) * sign with sign in {ONE, 0}
+  }
+}
+
+// the reference's one-Fr-per-bit aux tensors (zkrelu.cu:29-37) from the packed words: out[g*NB + i] = bit i of word g
+template <int NB, class WordT>
+__global__ void __launch_bounds__(256) k_relu_unpack(const WordT* __restrict__ packed, Fr* __restrict__ out, uint64_t total) {
+  const Fr one = fr_one(), zero = fr_zero();
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t word = packed[t / NB];
+    out[t] = ((word >> (uint32_t)(t % NB)) & 1u) ? one : zero;
   }
 }
 
@@ -276,6 +356,23 @@ int fc_forward(zk_ctx* ctx, const zk_fc* fc, const Fr* x, uint32_t xn, Fr* z) {
   if (xn % fc->in != 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");  // zkfc.cu:118
   uint32_t batch = xn / fc->in;
   if (batch == 0) return ZK_OK;
+  if (fc->wq && fc->in <= 16384) {  // quantised layer: exact int64 GEMM when the activations are small integers too
+    ZK_ALLOC(ctx, xi, int64_t, xn);
+    ZK_ALLOC(ctx, ovf, uint32_t, 1);
+    uint32_t h_ovf = 1;
+    ZK_TRY(dev_zero(ctx, ovf.get(), 4));
+    ZK_LAUNCH(ctx, "fc_forward_int", 40ull * xn, k_fr_to_i64, dim3(stream_grid(xn)), dim3(256), 0, x, xi.get(), xn, ovf.get());
+    ZK_TRY(dev_to_host(ctx, &h_ovf, ovf.get(), 4));
+    if (!h_ovf) {
+      const uint64_t zn = (uint64_t)batch * fc->out;
+      ZK_ALLOC(ctx, zi, int64_t, zn);
+      dim3 g((fc->out + ZK_GT - 1) / ZK_GT, (batch + ZK_GT - 1) / ZK_GT);
+      ZK_LAUNCH(ctx, "fc_forward_int", 8ull * xn + 2ull * fc->in * fc->out + 8ull * zn, k_gemm_i64_i16, g, dim3(256), 0, (const int64_t*)xi.get(), (const int16_t*)fc->wq,
+                zi.get(), batch, fc->in, fc->out);
+      ZK_LAUNCH(ctx, "fc_forward_int", 40ull * zn, k_i64_to_fr, dim3(stream_grid(zn)), dim3(256), 0, (const int64_t*)zi.get(), z, (uint32_t)zn);
+      return ZK_OK;
+    }
+  }
   dim3 grid((fc->out + ZK_TILE - 1) / ZK_TILE, (batch + ZK_TILE - 1) / ZK_TILE);
   uint64_t bytes = 32ull * ((uint64_t)xn + (uint64_t)fc->in * fc->out + (uint64_t)batch * fc->out);
   ZK_LAUNCH(ctx, "fc_matmul", bytes, k_fr_matmul, grid, dim3(256), 0, x, (const Fr*)fc->weights, z, batch, fc->in, fc->out);
@@ -345,8 +442,7 @@ int relu_forward(zk_ctx* ctx, zk_relu* relu, const Fr* x, uint32_t n, Fr* z) {
   if (n == 0) return ZK_OK;
   if (relu->cap < n) {  // reset_ptrs, zkrelu.cu:54-63
     relu->free_all();
-    bool ok = dev_alloc(ctx, (void**)&relu->sign, (size_t)n * sizeof(Fr)) == hipSuccess && dev_alloc(ctx, (void**)&relu->mag_bin, (size_t)n * 32 * sizeof(Fr)) == hipSuccess &&
-              dev_alloc(ctx, (void**)&relu->rem_bin, (size_t)n * 16 * sizeof(Fr)) == hipSuccess && dev_alloc(ctx, (void**)&relu->mag_packed, (size_t)n * 4) == hipSuccess &&
+    bool ok = dev_alloc(ctx, (void**)&relu->sign, (size_t)n * sizeof(Fr)) == hipSuccess && dev_alloc(ctx, (void**)&relu->mag_packed, (size_t)n * 4) == hipSuccess &&
               dev_alloc(ctx, (void**)&relu->rem_packed, (size_t)n * 2) == hipSuccess && dev_alloc(ctx, (void**)&relu->sign_packed, (size_t)n) == hipSuccess &&
               dev_alloc(ctx, (void**)&relu->oor, 16) == hipSuccess;
     if (!ok) {
@@ -356,12 +452,32 @@ int relu_forward(zk_ctx* ctx, zk_relu* relu, const Fr* x, uint32_t n, Fr* z) {
     relu->cap = n;
   }
   relu->n = n;
+  relu->bins_valid = false;  // mag_bin / rem_bin (48 field elements per input) are materialised on demand
   ZK_TRY(dev_zero(ctx, relu->oor, 4));
-  ZK_LAUNCH(ctx, "relu_forward", 32ull * 51 * n, k_relu, dim3(stream_grid(n)), dim3(256), 0, x, z, relu->sign, relu->mag_bin, relu->rem_bin, relu->mag_packed,
-            relu->rem_packed, relu->sign_packed, n, relu->oor);
+  ZK_LAUNCH(ctx, "relu_forward", 32ull * 3 * n, k_relu, dim3(stream_grid(n)), dim3(256), 0, x, z, relu->sign, relu->mag_packed, relu->rem_packed, relu->sign_packed, n, relu->oor);
   uint32_t oor = 0;
   ZK_TRY(dev_to_host(ctx, &oor, relu->oor, 4));
   if (oor) return ctx->fail(ZK_ERR_RANGE, "zkReLU: " + std::to_string(oor) + " input(s) outside the +-2^47 window (undefined in the reference)");
+  return ZK_OK;
+}
+
+// mag_bin (32 N) and rem_bin (16 N) as the reference stores them: built from the packed words the first time
+// something asks for them (the unpacked prover path, zk_relu_mag_bin / zk_relu_rem_bin)
+int relu_materialise_bins(zk_ctx* ctx, zk_relu* relu) {
+  if (relu->bins_valid || relu->n == 0) return ZK_OK;
+  const uint32_t n = relu->n;
+  if (relu->bins_cap < n) {
+    dev_free(ctx, relu->mag_bin);
+    dev_free(ctx, relu->rem_bin);
+    relu->mag_bin = relu->rem_bin = nullptr;
+    relu->bins_cap = 0;
+    if (dev_alloc(ctx, (void**)&relu->mag_bin, (size_t)n * 32 * sizeof(Fr)) != hipSuccess || dev_alloc(ctx, (void**)&relu->rem_bin, (size_t)n * 16 * sizeof(Fr)) != hipSuccess)
+      return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: zkReLU bit tensors");
+    relu->bins_cap = n;
+  }
+  ZK_LAUNCH(ctx, "relu_forward", 32ull * 32 * n, (k_relu_unpack<32, uint32_t>), dim3(stream_grid((uint64_t)n * 32)), dim3(256), 0, (const uint32_t*)relu->mag_packed, relu->mag_bin, (uint64_t)n * 32);
+  ZK_LAUNCH(ctx, "relu_forward", 32ull * 16 * n, (k_relu_unpack<16, uint16_t>), dim3(stream_grid((uint64_t)n * 16)), dim3(256), 0, (const uint16_t*)relu->rem_packed, relu->rem_bin, (uint64_t)n * 16);
+  relu->bins_valid = true;
   return ZK_OK;
 }
 
@@ -373,6 +489,7 @@ int relu_prove(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const Fr* z, uint3
   if ((uint64_t)n * 32 > 0xffffffffull) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   const uint32_t k = ceil_log2(n);
   const size_t add_fr = 3 * (k + 5) + 1 + 32 + 3 * (k + 4) + 1 + 16 + 3 * k + 2;
+  if (!ctx->relu_packed) ZK_TRY(relu_materialise_bins(ctx, const_cast<zk_relu*>(relu)));  // before recording starts
   ZK_TRY(tr->ensure(add_fr, 0));
   Fr* out = tr->fr_d + tr->n_fr;
   tr->n_fr += add_fr;

@@ -42,7 +42,8 @@ struct zk_fc {  // zkFC, zkfc.cuh:16-33: padded weights (Montgomery, [in][out]) 
 
 struct zk_relu {  // zkReLU, zkrelu.cuh:10-20: aux tensors of the last forward pass
   zk_ctx* ctx = nullptr;
-  uint32_t n = 0, cap = 0, serial = 0;
+  uint32_t n = 0, cap = 0, serial = 0, bins_cap = 0;
+  bool bins_valid = false;  // mag_bin / rem_bin hold the last forward pass's bits
   zk::Fr *sign = nullptr, *mag_bin = nullptr, *rem_bin = nullptr;
   uint32_t* mag_packed = nullptr;  // the same bits, 32 per element
   uint16_t* rem_packed = nullptr;  // 15 remainder bits + sign bit
@@ -53,7 +54,8 @@ struct zk_relu {  // zkReLU, zkrelu.cuh:10-20: aux tensors of the last forward p
     zk::dev_free(ctx, mag_packed); zk::dev_free(ctx, rem_packed); zk::dev_free(ctx, sign_packed); zk::dev_free(ctx, oor);
     sign = mag_bin = rem_bin = nullptr;
     mag_packed = nullptr; rem_packed = nullptr; sign_packed = nullptr; oor = nullptr;
-    cap = n = 0;
+    cap = n = bins_cap = 0;
+    bins_valid = false;
   }
 };
 
@@ -98,6 +100,7 @@ int fc_forward(zk_ctx* ctx, const zk_fc* fc, const Fr* x, uint32_t xn, Fr* z);
 int fc_prove(zk_ctx* ctx, zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint32_t zn, zk_gens* gens,
              const zk_fr* u_bs_h, const zk_fr* u_in_h, const zk_fr* u_out_h, zk_transcript* tr);
 int relu_forward(zk_ctx* ctx, zk_relu* relu, const Fr* x, uint32_t n, Fr* z);
+int relu_materialise_bins(zk_ctx* ctx, zk_relu* relu);
 int relu_prove(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const Fr* z, uint32_t n, const zk_fr* u_z_h, const zk_fr* v_z_h, const zk_fr* u_r_h,
                const zk_fr* v_r_h, const zk_fr* u_rec_h, const zk_fr* u_hp_h, const zk_fr* v_hp_h, zk_transcript* tr);
 // g1_kernels.hip
