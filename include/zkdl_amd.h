@@ -140,8 +140,12 @@ int zk_g1_to_affine(zk_ctx* ctx, const zk_g1j* a_d, uint32_t n, zk_g1a* out_d, u
 enum { ZK_MSM_LITERAL = 0, ZK_MSM_PIPPENGER = 1 };
 int zk_set_msm_mode(zk_ctx* ctx, int mode);
 int zk_set_msm_window(zk_ctx* ctx, uint32_t window_bits);   /* 0 = automatic */
-/* tunables, all on by default: "relu_packed" (ReLU aux sumchecks read the packed bits instead of the
- * one-Fr-per-bit tensors; same transcript) */
+/* Scheduling / representation switches, all on by default; none of them changes a transcript value:
+ *   "relu_packed"   ReLU aux sumchecks and partial_me read the packed bits instead of the one-Fr-per-bit tensors
+ *   "batch_layers"  zk_fc_prove / zk_relu_prove record their launches; flush/seal runs them batched across layers
+ *   "lanes"         worker streams (the recorder's groups, the G1 streams of zk_transcript_seal); off = one stream
+ *   "weights_q16"   layers created while set keep an int16 copy of quantised weights (|w| < 2^15) for the
+ *                   prover's two contractions of W and the integer forward pass */
 int zk_set_flag(zk_ctx* ctx, const char* name, int value);
 /* Commitment object (commitment.cuh:8-23): a generator tensor.  The handle keeps its own copy of the
  * n Jacobian generators and, for the PIPPENGER back end, lazily builds affine window tables

@@ -17,9 +17,11 @@
 //    in LDS (k_msm_sort); then each LANE takes a fixed-size chunk of L consecutive items of the sorted
 //    list (k_msm_accum: every lane does exactly L mixed adds whatever the digit distribution -- a
 //    partially filled top window or repeated scalars cannot overload a lane); buckets that straddle
-//    chunks are stitched from per-chunk head/tail partials (k_msm_combine).
-//  * Bucket reduction without a running-sum chain: sum_b b*S_b = sum_i 2^i * (sum of buckets whose
-//    index has bit i): c independent LDS tree sums (k_msm_bits) + a c-step Horner (k_msm_horner).
+//    chunks are stitched from per-chunk head/tail partials (k_msm_combine, four lanes per bucket).
+//  * Bucket reduction without a running-sum chain and without idle lanes: sum_b b*S_b with b = hi*2^L + lo is
+//    sum_lo lo*C_lo + 2^L * sum_hi hi*R_hi over row sums R and column sums C (k_msm_rowcol: 2B additions,
+//    four lanes per sum), then the two small weighted sums bit-slice by bit-slice plus a doubling + 4-level
+//    tree per MSM (k_msm_weighted).
 //  * Deferred batching.  Nothing in the protocol consumes a G1 value (the reference drops them all),
 //    so zkFC::prove only ENQUEUES its MSMs as jobs; every MSM of a whole proof (all layers, ~270 of
 //    them over 16 different tables) is executed by one sort/accum/combine/bits/horner sequence when the
