@@ -9,6 +9,8 @@ import bench
 zk = Zk(0)
 dims, batch = bench.WORKLOADS[os.environ.get("WORKLOAD", "mlp18m_b256")]
 wl = bench.Workload(zk, dims, batch, seed=0)
+if os.environ.get('LANES') == '0':
+    zk.set_flag('lanes', 0)                # every launch alone on the chip
 for it in range(3):                      # warm pools
     wl.prove(wl.challenges(it)); wl.tr.flush(); zk.sync()
 path = os.environ.get("ZKDL_PROF_TRACE")

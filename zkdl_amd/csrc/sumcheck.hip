@@ -21,6 +21,7 @@
 //
 // A length-2^24 binary sumcheck is 1 + 14 + 1 launches instead of the reference's ~2000.  Fr results
 // are canonical, so this re-association is bit-identical to the reference's order.
+#include <type_traits>
 #include <cstdlib>
 #include "ctx.hpp"
 #include "dev_util.hpp"
@@ -92,7 +93,22 @@ __device__ __forceinline__ void k_sc_round(uint32_t zk_nblk, const Fr* __restric
   Fr acc[3 * R];
 #pragma clang loop unroll(full)
   for (int i = 0; i < 3 * R; i++) acc[i] = fr_zero();
-  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < out_size; g += zk_nblk * blockDim.x) {
+  // Factored weights: the eq weight of pair h is A[h mod 2^c] * B[h >> c].  When the pairs divide evenly into
+  // contiguous per-workgroup ranges that do not straddle a multiple of 2^c (the first big rounds of every
+  // power-of-two table: most of the work), B is the same for the whole workgroup: lanes weight by A only and
+  // lane 0 multiplies the three workgroup sums by B once -- one product less per pair.
+  uint32_t P = 0;
+  bool fact = false;
+  if (R == 1 && MODE != SC_IP) {
+    P = out_size / zk_nblk;
+    fact = lv.c[2] != 0xffu && P * zk_nblk == out_size && P >= blockDim.x && P % blockDim.x == 0 && lv.c[0] < 32 && P <= (1u << lv.c[0]) && ((1u << lv.c[0]) % P) == 0;
+  }
+  // (two instantiations of the loop: a runtime select would let the compiler evaluate the product speculatively)
+  auto sweep = [&](auto FACT) {
+  const uint32_t g_first = FACT.value ? blockIdx.x * P + threadIdx.x : blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t g_end = FACT.value ? (blockIdx.x + 1) * P : out_size;
+  const uint32_t g_step = FACT.value ? blockDim.x : zk_nblk * blockDim.x;
+  for (uint32_t g = g_first; g < g_end; g += g_step) {
     Fr va[NE], vb[MODE == SC_BIN ? 1 : NE];
     const uint64_t base = (uint64_t)g * NE;
 #pragma clang loop unroll(full)
@@ -113,7 +129,8 @@ __device__ __forceinline__ void k_sc_round(uint32_t zk_nblk, const Fr* __restric
         // weighted coefficients w*c_q with the weight folded into a0 and da first: 5 (binary) / 6 (Hadamard)
         // products instead of 3 + 3 / 4 + 3
         if (MODE == SC_BIN) {
-          const Fr w = fr_mul(lv.A[j][h & mask], B[h >> lv.c[j]]);
+          Fr w = lv.A[j][h & mask];
+          if constexpr (!decltype(FACT)::value) w = fr_mul(w, B[h >> lv.c[j]]);
           const Fr a0w = fr_mul(a0, w), daw = fr_mul(da, w);
           c0 = fr_sub(fr_mul(a0w, a0), a0w);            // w (a0^2 - a0)
           c1 = fr_sub(fr_dbl(fr_mul(a0w, da)), daw);    // w (2 a0 da - da)
@@ -122,7 +139,8 @@ __device__ __forceinline__ void k_sc_round(uint32_t zk_nblk, const Fr* __restric
           Fr b0 = vb[2 * i], b1 = vb[2 * i + 1];
           Fr db = fr_sub(b1, b0);
           if (MODE == SC_HP) {
-            const Fr w = fr_mul(lv.A[j][h & mask], B[h >> lv.c[j]]);
+            Fr w = lv.A[j][h & mask];
+            if constexpr (!decltype(FACT)::value) w = fr_mul(w, B[h >> lv.c[j]]);
             const Fr a0w = fr_mul(a0, w), daw = fr_mul(da, w);
             c0 = fr_mul(a0w, b0);
             c1 = fr_add(fr_mul(a0w, db), fr_mul(daw, b0));
@@ -143,10 +161,16 @@ __device__ __forceinline__ void k_sc_round(uint32_t zk_nblk, const Fr* __restric
     a_out[g] = va[0];
     if (MODE != SC_BIN) b_out[g] = vb[0];
   }
+  };
+  if (fact) sweep(std::true_type{});
+  else sweep(std::false_type{});
 #pragma clang loop unroll(full)
   for (int i = 0; i < 3 * R; i++) {
     Fr t = block_sum_fr(acc[i], lds);
-    if (threadIdx.x == 0) partial[(uint64_t)blockIdx.x * (3 * R) + i] = t;
+    if (threadIdx.x == 0) {
+      if (fact) t = fr_mul(t, B[(blockIdx.x * P) >> lv.c[0]]);
+      partial[(uint64_t)blockIdx.x * (3 * R) + i] = t;
+    }
   }
   // workgroup 0 also closes the previous launch: its partials were completed by the kernel boundary
   if (blockIdx.x == 0 && prev_blocks) {
@@ -312,6 +336,8 @@ static int run_sumcheck(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n,
         lv.A[j] = tabA.get() + ((1u << s) - (1u << (s - (r + j))));
       }
     }
+    static const bool no_fact = getenv("ZKDL_SC_NOFACT") != nullptr;  // A/B switch for the factored-weight path
+    if (no_fact && R == 1) lv.c[2] = 0xffu;
     uint32_t grid = stream_grid(osz, 256, SC_MAX_BLOCKS);
     Fr* ao = a_slots[launch & 1];
     Fr* bo = b_slots[launch & 1];
