@@ -339,13 +339,13 @@ def main():
                 "launches_per_step": pv["launches"] // nprof, "measured": "standalone launches (worker streams off) after the timed region; rocprofv3 of `bench.py --serial` agrees",
                 "concurrent_avg_launch_ms": (prof_conc[dom]["ms"] / max(prof_conc[dom]["launches"], 1)) if dom in prof_conc else None,
                 "note": "this family is classified HBM-streaming (96*S bytes binary / 192*S ip+hadamard per table) but measures integer-VALU bound: "
-                        ">= 7 Fr Montgomery products (136 MACs each) per 96 B; see valu_roofline"}
+                        "6-7 Fr Montgomery products (136 MACs, ~330 instructions each) per 96 B, instruction-issue saturated in the large rounds; see valu_roofline"}
     # integer-VALU view of the same kernel and of the G1 (MSM) kernels: 32x32->64 MACs per second against the
     # measured v_mad_u64_u32 issue rate (tools/instr_rate.hip: 34 T lane-MAC/s at 8 waves/SIMD)
     FR_MACS, FP_MACS = 136, 300
     macs = None
     if dom.startswith("sumcheck_"):
-        per_pair = {"sumcheck_bin_round": 8, "sumcheck_hp_round": 9, "sumcheck_ip_round": 6}[dom] * FR_MACS
+        per_pair = {"sumcheck_bin_round": 7, "sumcheck_hp_round": 9, "sumcheck_ip_round": 6}[dom] * FR_MACS   # Fr products per pair (6 / 8 in the factored rounds)
         bytes_per_pair = 96 if dom == "sumcheck_bin_round" else 192
         macs = pv["bytes"] / bytes_per_pair * per_pair
     valu = {"kernel": dom, "peak_TMACps": 34.0, "achieved_TMACps": (macs / pv["ms"] / 1e9) if macs else None}
