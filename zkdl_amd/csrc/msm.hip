@@ -163,6 +163,104 @@ __device__ __forceinline__ uint32_t recode_digit(const Recoded& r, uint32_t c, u
   return (uint32_t)(d < 0 ? -d : d);
 }
 
+// ------------------------------------------------------------------ bucket coordinates: extended Jacobian (XYZZ)
+// Inside the MSM pipeline a point is (X, Y, ZZ, ZZZ) with x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2 (infinity: ZZ = 0):
+// a mixed addition costs 8M + 2S instead of madd-2007-bl's 7M + 4S and a full addition 12M + 2S instead of
+// 11M + 5S (EFD "xyzz": madd-2008-s, add-2008-s, dbl-2008-s-1).  Buckets, chunk partials and row/column sums
+// never leave the pipeline; the result goes back to Jacobian as (X*ZZ*ZZZ^2, Y*ZZ^3*ZZZ^2, ZZ*ZZZ) -- the same
+// group element, and the canonical (affine) form the transcript keeps is unaffected.
+struct alignas(16) G1X {
+  Fp x, y, zz, zzz;
+};
+__device__ __forceinline__ G1X g1x_zero() {
+  G1X r;
+  r.x = fp_zero();
+  r.y = fp_one();
+  r.zz = fp_zero();
+  r.zzz = fp_zero();
+  return r;
+}
+__device__ __forceinline__ G1X g1x_double(const G1X& a) {
+  if (l_is_zero(a.zz)) return a;
+  Fp u = fp_dbl(a.y);
+  Fp v = fp_sqr(u);
+  Fp w = fp_mul(u, v);
+  Fp s_ = fp_mul(a.x, v);
+  Fp xx = fp_sqr(a.x);
+  Fp m = fp_add(fp_dbl(xx), xx);
+  G1X o;
+  o.x = fp_sub(fp_sub(fp_sqr(m), s_), s_);
+  o.y = fp_sub(fp_mul(m, fp_sub(s_, o.x)), fp_mul(w, a.y));
+  o.zz = fp_mul(v, a.zz);
+  o.zzz = fp_mul(w, a.zzz);
+  return o;
+}
+__device__ __forceinline__ G1X g1x_madd(const G1X& a, const G1A& b) {
+  if (l_is_zero(a.zz)) {
+    G1X o;
+    o.x = b.x;
+    o.y = b.y;
+    o.zz = fp_one();
+    o.zzz = fp_one();
+    return o;
+  }
+  Fp u2 = fp_mul(b.x, a.zz);
+  Fp s2 = fp_mul(b.y, a.zzz);
+  Fp pd = fp_sub(u2, a.x);
+  Fp r = fp_sub(s2, a.y);
+  if (l_is_zero(pd)) return l_is_zero(r) ? g1x_double(a) : g1x_zero();
+  Fp pp = fp_sqr(pd);
+  Fp ppp = fp_mul(pd, pp);
+  Fp q = fp_mul(a.x, pp);
+  G1X o;
+  o.x = fp_sub(fp_sub(fp_sub(fp_sqr(r), ppp), q), q);
+  o.y = fp_sub(fp_mul(r, fp_sub(q, o.x)), fp_mul(a.y, ppp));
+  o.zz = fp_mul(a.zz, pp);
+  o.zzz = fp_mul(a.zzz, ppp);
+  return o;
+}
+__device__ __forceinline__ G1X g1x_add(const G1X& a, const G1X& b) {
+  if (l_is_zero(a.zz)) return b;
+  if (l_is_zero(b.zz)) return a;
+  Fp u1 = fp_mul(a.x, b.zz);
+  Fp u2 = fp_mul(b.x, a.zz);
+  Fp s1 = fp_mul(a.y, b.zzz);
+  Fp s2 = fp_mul(b.y, a.zzz);
+  Fp pd = fp_sub(u2, u1);
+  Fp r = fp_sub(s2, s1);
+  if (l_is_zero(pd)) return l_is_zero(r) ? g1x_double(a) : g1x_zero();
+  Fp pp = fp_sqr(pd);
+  Fp ppp = fp_mul(pd, pp);
+  Fp q = fp_mul(u1, pp);
+  G1X o;
+  o.x = fp_sub(fp_sub(fp_sub(fp_sqr(r), ppp), q), q);
+  o.y = fp_sub(fp_mul(r, fp_sub(q, o.x)), fp_mul(s1, ppp));
+  o.zz = fp_mul(fp_mul(a.zz, b.zz), pp);
+  o.zzz = fp_mul(fp_mul(a.zzz, b.zzz), ppp);
+  return o;
+}
+__device__ __forceinline__ G1J g1x_to_jacobian(const G1X& a) {
+  if (l_is_zero(a.zz)) return g1_zero();
+  Fp z = fp_mul(a.zz, a.zzz);                 // Z = ZZ*ZZZ: Z^2 = ZZ^2 ZZZ^2, Z^3 = ZZ^3 ZZZ^3
+  Fp t = fp_mul(a.zz, fp_sqr(a.zzz));         // ZZ ZZZ^2
+  G1J o;
+  o.x = fp_mul(a.x, t);                       // x Z^2 = X/ZZ * ZZ^2 ZZZ^2
+  o.y = fp_mul(a.y, fp_mul(t, fp_sqr(a.zz)));  // y Z^3 = Y/ZZZ * ZZ^3 ZZZ^3
+  o.z = z;
+  return o;
+}
+__device__ __forceinline__ G1X g1x_shfl_xor(const G1X& p, int mask) {
+  G1X r;
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    r.x.v[i] = __shfl_xor(p.x.v[i], mask, 64);
+    r.y.v[i] = __shfl_xor(p.y.v[i], mask, 64);
+    r.zz.v[i] = __shfl_xor(p.zz.v[i], mask, 64);
+    r.zzz.v[i] = __shfl_xor(p.zzz.v[i], mask, 64);
+  }
+  return r;
+}
+
 // ------------------------------------------------------------------ job table
 struct MsmJob {          // one MSM: out = sum_j scalar_j * base_j
   const G1A* table;      // [W][n] affine window table of the base set
@@ -242,7 +340,7 @@ __global__ void __launch_bounds__(1024) k_msm_sort(const MsmJob* __restrict__ jo
 // chunk is stored to buckets[]; a bucket that started earlier goes to head[chunk], one that continues
 // later to tail[chunk].  grid (chunk blocks, jobs).
 __global__ void __launch_bounds__(64) k_msm_accum(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ off,
-                                                   G1J* __restrict__ buckets, G1J* __restrict__ head, G1J* __restrict__ tail) {
+                                                   G1X* __restrict__ buckets, G1X* __restrict__ head, G1X* __restrict__ tail) {
   const uint32_t B = 1u << (c - 1);
   const uint32_t q = blockIdx.y;
   const MsmJob job = jobs[q];
@@ -264,14 +362,14 @@ __global__ void __launch_bounds__(64) k_msm_accum(const MsmJob* __restrict__ job
   uint32_t bend = o[b + 1];
   uint32_t run_start = cs;
   const uint32_t* items = idx + job.item_off;
-  G1J acc = g1_zero();
-  G1J* bk = buckets + (uint64_t)q * B;
+  G1X acc = g1x_zero();
+  G1X* bk = buckets + (uint64_t)q * B;
   for (uint32_t p = cs; p < ce; p++) {
     while (p >= bend) {  // bucket b ends here (possibly followed by empty buckets)
       if (p > run_start) {
         if (run_start == o[b]) bk[b - 1] = acc;                     // complete: started and ended inside this chunk
         else head[job.chunk_off + t] = acc;                          // started in an earlier chunk
-        acc = g1_zero();
+        acc = g1x_zero();
       }
       b++;
       bend = o[b + 1];
@@ -281,7 +379,7 @@ __global__ void __launch_bounds__(64) k_msm_accum(const MsmJob* __restrict__ job
     uint32_t j = it & 0xfffffu, w = (it >> 20) & 0x7ffu;
     G1A P = job.table[(uint64_t)w * job.n + j];
     if (it >> 31) P.y = fp_neg(P.y);
-    acc = g1_add_mixed(acc, P);
+    acc = g1x_madd(acc, P);
   }
   // last run of the chunk: [run_start, ce) of bucket b
   bool starts = run_start == o[b], ends = ce == bend;
@@ -290,22 +388,12 @@ __global__ void __launch_bounds__(64) k_msm_accum(const MsmJob* __restrict__ job
   else tail[job.chunk_off + t] = acc;                        // starts inside, continues into the next chunk
 }
 
-__device__ __forceinline__ G1J g1_shfl_xor(const G1J& p, int mask) {
-  G1J r;
-#pragma unroll
-  for (int i = 0; i < 12; i++) {
-    r.x.v[i] = __shfl_xor(p.x.v[i], mask, 64);
-    r.y.v[i] = __shfl_xor(p.y.v[i], mask, 64);
-    r.z.v[i] = __shfl_xor(p.z.v[i], mask, 64);
-  }
-  return r;
-}
 // four lanes per (job, bucket): empty -> infinity; split across chunks -> sum of the chunk partials, each lane
 // adding every fourth partial and two butterfly steps joining them.  (The top window of a scalar < r/2 has one
 // or two bits of entropy, so for some window widths half of all points of an MSM land in one bucket: a single
 // lane would walk ~100 additions there.)
-__global__ void __launch_bounds__(64) k_msm_combine(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ off, G1J* __restrict__ buckets,
-                                                     const G1J* __restrict__ head, const G1J* __restrict__ tail) {
+__global__ void __launch_bounds__(64) k_msm_combine(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ off, G1X* __restrict__ buckets,
+                                                     const G1X* __restrict__ head, const G1X* __restrict__ tail) {
   const uint32_t B = 1u << (c - 1);
   const uint32_t q = blockIdx.y;
   const uint32_t sub = threadIdx.x & 3u;
@@ -315,7 +403,7 @@ __global__ void __launch_bounds__(64) k_msm_combine(const MsmJob* __restrict__ j
   const uint32_t* o = off + (uint64_t)q * (B + 2);
   const uint32_t base = o[1];
   const uint32_t s = live ? o[b] : 0, e = live ? o[b + 1] : 0;
-  G1J acc = g1_zero();
+  G1X acc = g1x_zero();
   bool store = live && s == e;  // empty bucket: infinity
   if (live && s != e) {
     const uint32_t t0 = (s - base) / MSM_CHUNK, t1 = (e - 1 - base) / MSM_CHUNK;
@@ -323,11 +411,11 @@ __global__ void __launch_bounds__(64) k_msm_combine(const MsmJob* __restrict__ j
       store = true;
       // chunk t0 holds the bucket's first piece: a tail unless the bucket starts exactly at the chunk start
       if (sub == 0) acc = ((s - base) == t0 * MSM_CHUNK) ? head[job.chunk_off + t0] : tail[job.chunk_off + t0];
-      for (uint32_t t = t0 + 1 + sub; t <= t1; t += 4) acc = g1_add(acc, head[job.chunk_off + t]);
+      for (uint32_t t = t0 + 1 + sub; t <= t1; t += 4) acc = g1x_add(acc, head[job.chunk_off + t]);
     }
   }
-  acc = g1_add(acc, g1_shfl_xor(acc, 1));
-  acc = g1_add(acc, g1_shfl_xor(acc, 2));
+  acc = g1x_add(acc, g1x_shfl_xor(acc, 1));
+  acc = g1x_add(acc, g1x_shfl_xor(acc, 2));
   if (store && sub == 0) buckets[(uint64_t)q * B + (b - 1)] = acc;
 }
 
@@ -350,65 +438,65 @@ static ReduceShape reduce_shape(uint32_t c) {
   return s;
 }
 // RC[q*nsums + s]: four lanes per sum, each adds every fourth term, then two butterfly steps.  grid (blocks, jobs)
-__global__ void __launch_bounds__(64) k_msm_rowcol(const G1J* __restrict__ buckets, uint32_t c, ReduceShape sh, G1J* __restrict__ RC) {
+__global__ void __launch_bounds__(64) k_msm_rowcol(const G1X* __restrict__ buckets, uint32_t c, ReduceShape sh, G1X* __restrict__ RC) {
   const uint32_t B = 1u << (c - 1);
   const uint32_t q = blockIdx.y;
   const uint32_t lane = blockIdx.x * 64u + threadIdx.x;
   const uint32_t s = lane >> 2, t = lane & 3u;
-  const G1J* bk = buckets + (uint64_t)q * B;
-  G1J acc = g1_zero();
+  const G1X* bk = buckets + (uint64_t)q * B;
+  G1X acc = g1x_zero();
   if (s < sh.nhi) {  // row hi = s
     for (uint32_t lo = t; lo < sh.nlo; lo += 4) {
       uint32_t b = s * sh.nlo + lo;
-      if (b >= 1 && b <= B) acc = g1_add(acc, bk[b - 1]);
+      if (b >= 1 && b <= B) acc = g1x_add(acc, bk[b - 1]);
     }
   } else if (s < sh.nsums) {  // column lo = s - nhi
     const uint32_t lo = s - sh.nhi;
     for (uint32_t hi = t; hi < sh.nhi; hi += 4) {
       uint32_t b = hi * sh.nlo + lo;
-      if (b >= 1 && b <= B) acc = g1_add(acc, bk[b - 1]);
+      if (b >= 1 && b <= B) acc = g1x_add(acc, bk[b - 1]);
     }
   }
-  acc = g1_add(acc, g1_shfl_xor(acc, 1));
-  acc = g1_add(acc, g1_shfl_xor(acc, 2));
+  acc = g1x_add(acc, g1x_shfl_xor(acc, 1));
+  acc = g1x_add(acc, g1x_shfl_xor(acc, 2));
   if (s < sh.nsums && t == 0) RC[(uint64_t)q * sh.nsums + s] = acc;
 }
 // one wave per job: lanes 4j..4j+3 build slice T_j, lane j then doubles it j times, and a 4-level tree adds them
-__global__ void __launch_bounds__(64) k_msm_weighted(const MsmJob* __restrict__ jobs, const G1J* __restrict__ RC, uint32_t c, ReduceShape sh) {
-  __shared__ G1J T[16];
+__global__ void __launch_bounds__(64) k_msm_weighted(const MsmJob* __restrict__ jobs, const G1X* __restrict__ RC, uint32_t c, ReduceShape sh) {
+  __shared__ G1X T[16];
   const uint32_t q = blockIdx.x, lane = threadIdx.x;
   const uint32_t j = lane >> 2, t = lane & 3u;
-  const G1J* rc = RC + (uint64_t)q * sh.nsums;
-  G1J acc = g1_zero();
+  const G1X* rc = RC + (uint64_t)q * sh.nsums;
+  G1X acc = g1x_zero();
   // the m-th index with bit i set is  ((m >> i) << (i + 1)) | 1 << i | (m & (2^i - 1)):  every iteration adds
   if (j < sh.LB) {  // column weights: bit j of lo
     for (uint32_t m = t; m < sh.nlo / 2; m += 4) {
       uint32_t lo = ((m >> j) << (j + 1)) | (1u << j) | (m & ((1u << j) - 1u));
-      acc = g1_add(acc, rc[sh.nhi + lo]);
+      acc = g1x_add(acc, rc[sh.nhi + lo]);
     }
   } else if (j < c) {  // row weights: bit j - LB of hi (hi <= nhi - 1, a power of two)
     const uint32_t i = j - sh.LB;
     for (uint32_t m = t; m < sh.nhi - 1; m += 4) {
       uint32_t hi = ((m >> i) << (i + 1)) | (1u << i) | (m & ((1u << i) - 1u));
-      if (hi < sh.nhi) acc = g1_add(acc, rc[hi]);
+      if (hi < sh.nhi) acc = g1x_add(acc, rc[hi]);
     }
   }
-  acc = g1_add(acc, g1_shfl_xor(acc, 1));
-  acc = g1_add(acc, g1_shfl_xor(acc, 2));
-  if (t == 0 && j < 16) T[j] = j < c ? acc : g1_zero();
+  acc = g1x_add(acc, g1x_shfl_xor(acc, 1));
+  acc = g1x_add(acc, g1x_shfl_xor(acc, 2));
+  if (t == 0 && j < 16) T[j] = j < c ? acc : g1x_zero();
   __syncthreads();
   if (lane < 16) {
     acc = T[lane];
     const uint32_t nd = lane < c ? lane : 0;  // lanes >= c hold infinity
-    for (uint32_t d = 0; d < nd; d++) acc = g1_double(acc);
+    for (uint32_t d = 0; d < nd; d++) acc = g1x_double(acc);
     T[lane] = acc;
   }
   __syncthreads();
   for (uint32_t st = 8; st > 0; st >>= 1) {
-    if (lane < st) T[lane] = g1_add(T[lane], T[lane + st]);
+    if (lane < st) T[lane] = g1x_add(T[lane], T[lane + st]);
     __syncthreads();
   }
-  if (lane == 0) *jobs[q].out = T[0];
+  if (lane == 0) *jobs[q].out = g1x_to_jacobian(T[0]);
 }
 
 // canonical form in place: affine x, y with Z = ONE; infinity as {0, ONE, 0}
@@ -481,19 +569,19 @@ int msm_run_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs, uint32_t c) 
   }
   ZK_ALLOC(ctx, idx, uint32_t, items);
   ZK_ALLOC(ctx, off, uint32_t, (size_t)nj * (B + 2));
-  ZK_ALLOC(ctx, buckets, G1J, (size_t)nj * B);
-  ZK_ALLOC(ctx, head, G1J, chunks);
-  ZK_ALLOC(ctx, tail, G1J, chunks);
-  ZK_ALLOC(ctx, RC, G1J, (size_t)nj * reduce_shape(c).nsums);
+  ZK_ALLOC(ctx, buckets, G1X, (size_t)nj * B);
+  ZK_ALLOC(ctx, head, G1X, chunks);
+  ZK_ALLOC(ctx, tail, G1X, chunks);
+  ZK_ALLOC(ctx, RC, G1X, (size_t)nj * reduce_shape(c).nsums);
   size_t lds = (size_t)(B + 2 + 1024) * 4;
   ZK_LAUNCH(ctx, "msm_sort", 32ull * pairs + 4ull * items, k_msm_sort, dim3(nj), dim3(1024), lds, (const MsmJob*)djobs.get(), c, K, idx.get(), off.get());
   ZK_LAUNCH(ctx, "msm_accum", 100ull * items, k_msm_accum, dim3((max_chunks + 63) / 64, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, (const uint32_t*)idx.get(),
             (const uint32_t*)off.get(), buckets.get(), head.get(), tail.get());
-  ZK_LAUNCH(ctx, "msm_combine", 144ull * nj * B, k_msm_combine, dim3((B + 15) / 16, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, (const uint32_t*)off.get(), buckets.get(),
-            (const G1J*)head.get(), (const G1J*)tail.get());
+  ZK_LAUNCH(ctx, "msm_combine", 192ull * nj * B, k_msm_combine, dim3((B + 15) / 16, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, (const uint32_t*)off.get(), buckets.get(),
+            (const G1X*)head.get(), (const G1X*)tail.get());
   const ReduceShape sh = reduce_shape(c);
-  ZK_LAUNCH(ctx, "msm_bucket_reduce", 144ull * nj * B, k_msm_rowcol, dim3((sh.nsums * 4 + 63) / 64, nj), dim3(64), 0, (const G1J*)buckets.get(), c, sh, RC.get());
-  ZK_LAUNCH(ctx, "msm_horner", 144ull * nj * sh.nsums, k_msm_weighted, dim3(nj), dim3(64), 0, (const MsmJob*)djobs.get(), (const G1J*)RC.get(), c, sh);
+  ZK_LAUNCH(ctx, "msm_bucket_reduce", 192ull * nj * B, k_msm_rowcol, dim3((sh.nsums * 4 + 63) / 64, nj), dim3(64), 0, (const G1X*)buckets.get(), c, sh, RC.get());
+  ZK_LAUNCH(ctx, "msm_horner", 192ull * nj * sh.nsums, k_msm_weighted, dim3(nj), dim3(64), 0, (const MsmJob*)djobs.get(), (const G1X*)RC.get(), c, sh);
   return ZK_OK;
 }
 
