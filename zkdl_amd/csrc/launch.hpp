@@ -88,7 +88,7 @@ struct Recorder {
 };
 static constexpr size_t REC_BLOB_CAP = 4u << 20;
 // groups (= streams) the layers' independent pieces are spread over, balanced on the 18M-parameter MLP:
-// FC sumcheck + Z(u) | FC opening + ReLU Hadamard sumcheck | ReLU magnitude bits | ReLU remainder bits + partial_me's
+// FC sumcheck + Z(u) + ReLU partial_me's | FC opening + ReLU Hadamard sumcheck | ReLU magnitude bits | ReLU remainder bits
 enum { REC_GROUP_FC_A = 0, REC_GROUP_FC_OPEN = 1, REC_GROUP_RELU_MAG = 2, REC_GROUP_RELU_REM = 3 };
 
 int rec_begin_chain(zk_ctx* ctx, Recorder* r, uint32_t group = 0);  // sets ctx->rec; allocates the blob on first use

@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(1024) k_msm_sort(const MsmJob* __restrict__ jo
 // Each lane adds MSM_CHUNK consecutive items of the bucket-sorted list.  A bucket wholly inside the
 // chunk is stored to buckets[]; a bucket that started earlier goes to head[chunk], one that continues
 // later to tail[chunk].  grid (chunk blocks, jobs).
-__global__ void __launch_bounds__(64) k_msm_accum(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ off,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) k_msm_accum(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ off,
                                                    G1X* __restrict__ buckets, G1X* __restrict__ head, G1X* __restrict__ tail) {
   const uint32_t B = 1u << (c - 1);
   const uint32_t q = blockIdx.y;
