@@ -143,12 +143,12 @@ __device__ __forceinline__ void k_sc_round(uint32_t zk_nblk, const Fr* __restric
             if constexpr (!decltype(FACT)::value) w = fr_mul(w, B[h >> lv.c[j]]);
             const Fr a0w = fr_mul(a0, w), daw = fr_mul(da, w);
             c0 = fr_mul(a0w, b0);
-            c1 = fr_add(fr_mul(a0w, db), fr_mul(daw, b0));
             c2 = fr_mul(daw, db);
+            c1 = fr_sub(fr_sub(fr_mul(fr_add(a0w, daw), b1), c0), c2);  // a0w db + daw b0 = (a0w + daw) b1 - c0 - c2
           } else {
             c0 = fr_mul(a0, b0);
-            c1 = fr_add(fr_mul(a0, db), fr_mul(b0, da));
             c2 = fr_mul(da, db);
+            c1 = fr_sub(fr_sub(fr_mul(a1, b1), c0), c2);  // a0 db + b0 da = a1 b1 - c0 - c2
           }
           vb[i] = fr_add(b0, fr_mul(x[j], db));
         }
@@ -238,8 +238,8 @@ __device__ __forceinline__ void k_sc_tail(uint32_t zk_nblk, const Fr* __restrict
         Fr b1 = g1 < sz ? tb[g1] : fr_zero();
         Fr db = fr_sub(b1, b0);
         c0 = fr_mul(a0, b0);
-        c1 = fr_add(fr_mul(a0, db), fr_mul(b0, da));
         c2 = fr_mul(da, db);
+        c1 = fr_sub(fr_sub(fr_mul(a1, b1), c0), c2);
         nb = g1 < sz ? fr_add(b0, fr_mul(x, db)) : fr_sub(b0, fr_mul(x, b0));
       }
       na = g1 < sz ? fr_add(a0, fr_mul(x, da)) : fr_sub(a0, fr_mul(x, a0));
