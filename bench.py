@@ -49,7 +49,7 @@ class Workload:
     layers, quantised input, inference (Z_i, A_i, aux bits).  Synthetic weights in model.py's init
     distribution, synthetic N(0,1) inputs; seeded per rank so ranks prove independent batches."""
 
-    def __init__(self, zk, dims, batch, seed):
+    def __init__(self, zk, dims, batch, seed, inflight=2):
         from oracle_free_gen import generator_jac
         from zkdl_amd.capi import FC, ReLU, Transcript
         self.zk, self.dims, self.batch = zk, dims, batch
@@ -92,7 +92,9 @@ class Workload:
         self.Yhat = zk.fr_unmont(self.fcs[L - 1].forward(cur))                   # demo.cu:119
         zk.sync()
         t_fwd = time.perf_counter() - t0
-        self.trs = [Transcript(zk), Transcript(zk)]   # alternated: proof i's G1 phase runs under proof i+1's Fr phase
+        # rotated: proof i's G1 phase runs under the Fr phases of the following proofs; a transcript is reused
+        # only after its own G1 phase has finished, so with T transcripts the period is >= (Fr + G1 chain) / T
+        self.trs = [Transcript(zk) for _ in range(max(2, inflight))]
         self.tr = self.trs[0]
         self.info = dict(setup_generators_s=t_gen, setup_commit_s=t_commit, commit_pairs=pairs,
                          commit_mops=pairs / t_commit / 1e6, inference_s=t_fwd)
@@ -198,6 +200,7 @@ def main():
     ap.add_argument("--workload", default="mlp18m_b256", choices=sorted(WORKLOADS))
     ap.add_argument("--msm", default="pippenger", choices=["pippenger", "literal"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=3, help="transcripts rotated by the pipelined loop (proofs whose G1 phase may still be running)")
     ap.add_argument("--serial", action="store_true", help="no worker streams at all: every launch runs alone (the schedule the roofline durations are measured under)")
     ap.add_argument("--msm-window", type=int, default=0, help="force the Pippenger window width (0 = library default)")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every proof on the main stream (no overlap of proof i's G1 phase with proof i+1's Fr phase)")
@@ -228,14 +231,14 @@ def main():
     if args.msm_window:
         zk.set_msm_window(args.msm_window)
     dims, batch = WORKLOADS[args.workload]
-    wl = Workload(zk, dims, batch, seed=rank)
+    wl = Workload(zk, dims, batch, seed=rank, inflight=args.inflight)
 
     # The G1 phase of every proof (MSM batch, canonicalisation, digest) and the all-reduce of its digest are
     # ordered on the library's G1 stream; the Fr phase of the next proof runs beside them on the worker lanes.
     pipelined = not args.no_pipeline and not args.serial
     if args.serial:
         zk.set_flag("lanes", 0)
-    aggs = [torch.zeros(8, dtype=torch.int64, device="cuda") for _ in range(2)]
+    aggs = [torch.zeros(8, dtype=torch.int64, device="cuda") for _ in range(max(2, args.inflight))]
     ext_streams = {}
     torch.cuda.synchronize()
 
@@ -246,8 +249,8 @@ def main():
 
     def step(i):
         chal = wl.challenges(i)
-        tr = wl.trs[i & 1] if pipelined else wl.tr
-        agg = aggs[i & 1]
+        tr = wl.trs[i % len(wl.trs)] if pipelined else wl.tr
+        agg = aggs[i % len(aggs)]
         wl.prove(chal, tr)
         if pipelined:
             tr.seal(agg.data_ptr())
