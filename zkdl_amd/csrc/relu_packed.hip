@@ -48,18 +48,25 @@ __device__ __forceinline__ void bin_coefs(const Fr& a0, const Fr& a1, Fr& c0, Fr
 }
 
 // table layout (in Fr elements), P_r = nb >> (r+1) pairs per element in round r
+// Compact tables: of a pair's three coefficients, c0 = a0^2 - a0 depends on the LOW half of the bit group only
+// and p(1) = c0 + c1 + c2 = a1^2 - a1 on the HIGH half only.  So per position the prescaled tables are
+//   C2[group] (16 / 256 entries), C0[low half] (4 / 16), P1[high half] (4 / 16)
+// and c1 is recovered per element as sum P1 - sum C0 - sum C2: 1616 entries (51 KB) instead of 3728 (119 KB) for
+// 32-bit words -- three workgroups of 256 lanes per CU instead of one of 512.
 struct PackedLayout {
   uint32_t lognb, P0, P1, P2;
   uint32_t off_e0, off_t1, off_t2, off_v3, total;
 };
+static constexpr uint32_t T1_STRIDE = 16 + 4 + 4;      // per position: C2[16] | C0[4] | P1[4]
+static constexpr uint32_t T2_STRIDE = 256 + 16 + 16;   // per position: C2[256] | C0[16] | P1[16]
 static PackedLayout packed_layout(uint32_t nb) {
   PackedLayout L;
   L.lognb = nb == 32 ? 5 : 4;
   L.P0 = nb / 2; L.P1 = nb / 4; L.P2 = nb / 8;
   L.off_e0 = 0;
   L.off_t1 = 16;
-  L.off_t2 = L.off_t1 + L.P1 * 3 * 16;
-  L.off_v3 = L.off_t2 + L.P2 * 3 * 256;
+  L.off_t2 = L.off_t1 + L.P1 * T1_STRIDE;
+  L.off_v3 = L.off_t2 + L.P2 * T2_STRIDE;
   L.total = L.off_v3 + 256;
   return L;
 }
@@ -72,18 +79,34 @@ __device__ __forceinline__ void k_binp_prep(uint32_t zk_nblk, const Fr* __restri
   for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += zk_nblk * blockDim.x) {
     if (idx < L.off_t1) {  // Elo_0[i'] = eq(u[1..lognb), i')
       tab[idx] = idx < L.P0 ? eq_prod(u + 1, L.lognb - 1, idx) : fr_zero();
-    } else if (idx < L.off_t2) {  // TS1[i'][q][nibble] = eq(u[2..lognb), i') * coef_q(a0, a1)
-      uint32_t t = idx - L.off_t1, nib = t & 15u, q = (t >> 4) % 3u, ip = t / 48u;
-      Fr a0 = fold_bits(nib & 3u, 1, v), a1 = fold_bits(nib >> 2, 1, v);
-      Fr c0, c1, c2;
-      bin_coefs(a0, a1, c0, c1, c2);
-      tab[idx] = fr_mul(eq_prod(u + 2, L.lognb - 2, ip), q == 0 ? c0 : q == 1 ? c1 : c2);
-    } else if (idx < L.off_v3) {  // TS2[i'][q][byte] = eq(u[3..lognb), i') * coef_q(a0, a1)
-      uint32_t t = idx - L.off_t2, byte = t & 255u, q = (t >> 8) % 3u, ip = t / 768u;
-      Fr a0 = fold_bits(byte & 15u, 2, v), a1 = fold_bits(byte >> 4, 2, v);
-      Fr c0, c1, c2;
-      bin_coefs(a0, a1, c0, c1, c2);
-      tab[idx] = fr_mul(eq_prod(u + 3, L.lognb - 3, ip), q == 0 ? c0 : q == 1 ? c1 : c2);
+    } else if (idx < L.off_t2) {  // round 1, position i' = t / 24: weights eq(u[2..lognb), i')
+      uint32_t t = idx - L.off_t1, ip = t / T1_STRIDE, e = t % T1_STRIDE;
+      Fr wgt = eq_prod(u + 2, L.lognb - 2, ip);
+      Fr val;
+      if (e < 16) {  // C2[nibble]
+        Fr a0 = fold_bits(e & 3u, 1, v), a1 = fold_bits(e >> 2, 1, v);
+        Fr c0, c1, c2;
+        bin_coefs(a0, a1, c0, c1, c2);
+        val = c2;
+      } else {       // C0[low 2 bits] / P1[high 2 bits]: x^2 - x of the half's folded value
+        Fr x = fold_bits((e - 16) & 3u, 1, v);
+        val = fr_sub(fr_sqr(x), x);
+      }
+      tab[idx] = fr_mul(wgt, val);
+    } else if (idx < L.off_v3) {  // round 2, position i' = t / 288: weights eq(u[3..lognb), i')
+      uint32_t t = idx - L.off_t2, ip = t / T2_STRIDE, e = t % T2_STRIDE;
+      Fr wgt = eq_prod(u + 3, L.lognb - 3, ip);
+      Fr val;
+      if (e < 256) {  // C2[byte]
+        Fr a0 = fold_bits(e & 15u, 2, v), a1 = fold_bits(e >> 4, 2, v);
+        Fr c0, c1, c2;
+        bin_coefs(a0, a1, c0, c1, c2);
+        val = c2;
+      } else {        // C0[low nibble] / P1[high nibble]
+        Fr x = fold_bits((e - 256) & 15u, 2, v);
+        val = fr_sub(fr_sqr(x), x);
+      }
+      tab[idx] = fr_mul(wgt, val);
     } else if (idx < L.total) {  // V3[byte]: the table after three folds
       tab[idx] = fold_bits(idx - L.off_v3, 3, v);
     } else if (idx < L.total + nAH) {
@@ -120,23 +143,26 @@ __device__ __forceinline__ void k_binp_rounds(uint32_t zk_nblk, const WordT* __r
 #pragma unroll 4
     for (uint32_t ip = 0; ip < NB / 2; ip++)
       if ((x >> (2 * ip)) & 1u) f[0] = fr_add(f[0], E0[ip]);
+    Fr p1a = fr_zero(), p1b = fr_zero();  // sums of p(1) over the positions: c1 = p(1) - c0 - c2
 #pragma unroll 2
     for (uint32_t ip = 0; ip < NB / 4; ip++) {
       const uint32_t nib = (word >> (4 * ip)) & 15u;
-      const Fr* t = T1 + ip * 48 + nib;
-      f[1] = fr_add(f[1], t[0]);
-      f[2] = fr_add(f[2], t[16]);
-      f[3] = fr_add(f[3], t[32]);
+      const Fr* t = T1 + ip * T1_STRIDE;
+      f[3] = fr_add(f[3], t[nib]);
+      f[1] = fr_add(f[1], t[16 + (nib & 3u)]);
+      p1a = fr_add(p1a, t[20 + (nib >> 2)]);
     }
+    f[2] = fr_sub(fr_sub(p1a, f[1]), f[3]);
 #pragma unroll
     for (uint32_t ip = 0; ip < NB / 8; ip++) {
       const uint32_t byte = (word >> (8 * ip)) & 255u;
-      const Fr* t = T2 + ip * 768 + byte;
-      f[4] = fr_add(f[4], t[0]);
-      f[5] = fr_add(f[5], t[256]);
-      f[6] = fr_add(f[6], t[512]);
+      const Fr* t = T2 + ip * T2_STRIDE;
+      f[6] = fr_add(f[6], t[byte]);
+      f[4] = fr_add(f[4], t[256 + (byte & 15u)]);
+      p1b = fr_add(p1b, t[272 + (byte >> 4)]);
       a3[(uint64_t)g * (NB / 8) + ip] = V3[byte];
     }
+    f[5] = fr_sub(fr_sub(p1b, f[4]), f[6]);
 #pragma unroll
     for (int i = 0; i < 7; i++) acc[i] = fr_add(acc[i], fr_mul(w, f[i]));
   }
@@ -221,26 +247,26 @@ int binp_sumcheck_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb, 
   ZK_LAUNCHB(ctx, "binp_prep", 32ull * nprep, 256, k_binp_prep, dim3(stream_grid(nprep, 256, 64)), 0, u_d, v_d, k, L, ch, tab.get(), AH.get(), BH.get());
   const uint32_t a3n = n * (nb / 8);
   ZK_ALLOC(ctx, a3, Fr, a3n);
-  const uint32_t grid = stream_grid(n, 512, 256);
+  const uint32_t grid = stream_grid(n, 256, 768);
   ZK_ALLOC(ctx, partial, Fr, (size_t)grid * 7);
   const size_t lds = (size_t)(L.total + 8) * sizeof(Fr);
   static bool attr32 = false, attr16 = false;
   uint64_t bytes = (uint64_t)n * (nb / 8) + 32ull * a3n;
   if (nb == 32) {
     if (!attr32) {
-      zk::Kern<512, &k_binp_rounds<32, uint32_t>>::set_max_lds(lds);
+      zk::Kern<256, &k_binp_rounds<32, uint32_t>>::set_max_lds(lds);
       (void)hipGetLastError();
       attr32 = true;
     }
-    ZK_LAUNCHB(ctx, "binp_rounds", bytes, 512, (k_binp_rounds<32, uint32_t>), dim3(grid), lds, (const uint32_t*)packed, n, L, (const Fr*)tab.get(), (const Fr*)AH.get(),
+    ZK_LAUNCHB(ctx, "binp_rounds", bytes, 256, (k_binp_rounds<32, uint32_t>), dim3(grid), lds, (const uint32_t*)packed, n, L, (const Fr*)tab.get(), (const Fr*)AH.get(),
               (const Fr*)BH.get(), ch, a3.get(), partial.get());
   } else {
     if (!attr16) {
-      zk::Kern<512, &k_binp_rounds<16, uint16_t>>::set_max_lds(lds);
+      zk::Kern<256, &k_binp_rounds<16, uint16_t>>::set_max_lds(lds);
       (void)hipGetLastError();
       attr16 = true;
     }
-    ZK_LAUNCHB(ctx, "binp_rounds", bytes, 512, (k_binp_rounds<16, uint16_t>), dim3(grid), lds, (const uint16_t*)packed, n, L, (const Fr*)tab.get(), (const Fr*)AH.get(),
+    ZK_LAUNCHB(ctx, "binp_rounds", bytes, 256, (k_binp_rounds<16, uint16_t>), dim3(grid), lds, (const uint16_t*)packed, n, L, (const Fr*)tab.get(), (const Fr*)AH.get(),
               (const Fr*)BH.get(), ch, a3.get(), partial.get());
   }
   ZK_LAUNCHB(ctx, "binp_finish", 32ull * 7 * grid, 256, k_binp_finish, dim3(1), 0, (const Fr*)partial.get(), grid, proof_d);
