@@ -388,16 +388,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
   else tail[job.chunk_off + t] = acc;                        // starts inside, continues into the next chunk
 }
 
-// four lanes per (job, bucket): empty -> infinity; split across chunks -> sum of the chunk partials, each lane
-// adding every fourth partial and two butterfly steps joining them.  (The top window of a scalar < r/2 has one
+// LPB lanes per (job, bucket): empty -> infinity; split across chunks -> sum of the chunk partials, each lane
+// adding every LPB-th partial and log2(LPB) butterfly steps joining them.  (The top window of a scalar < r/2 has one
 // or two bits of entropy, so for some window widths half of all points of an MSM land in one bucket: a single
 // lane would walk ~100 additions there.)
+template <int LPB>  // lanes per bucket: 2 when buckets span few chunks, 4 when a near-empty top window makes hot buckets
 __global__ void __launch_bounds__(64) k_msm_combine(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ off, G1X* __restrict__ buckets,
                                                      const G1X* __restrict__ head, const G1X* __restrict__ tail) {
   const uint32_t B = 1u << (c - 1);
   const uint32_t q = blockIdx.y;
-  const uint32_t sub = threadIdx.x & 3u;
-  const uint32_t b = blockIdx.x * 16u + (threadIdx.x >> 2) + 1;
+  const uint32_t sub = threadIdx.x % LPB;
+  const uint32_t b = blockIdx.x * (64u / LPB) + (threadIdx.x / LPB) + 1;
   const bool live = b <= B;
   const MsmJob job = jobs[q];
   const uint32_t* o = off + (uint64_t)q * (B + 2);
@@ -411,11 +412,11 @@ __global__ void __launch_bounds__(64) k_msm_combine(const MsmJob* __restrict__ j
       store = true;
       // chunk t0 holds the bucket's first piece: a tail unless the bucket starts exactly at the chunk start
       if (sub == 0) acc = ((s - base) == t0 * MSM_CHUNK) ? head[job.chunk_off + t0] : tail[job.chunk_off + t0];
-      for (uint32_t t = t0 + 1 + sub; t <= t1; t += 4) acc = g1x_add(acc, head[job.chunk_off + t]);
+      for (uint32_t t = t0 + 1 + sub; t <= t1; t += LPB) acc = g1x_add(acc, head[job.chunk_off + t]);
     }
   }
-  acc = g1x_add(acc, g1x_shfl_xor(acc, 1));
-  acc = g1x_add(acc, g1x_shfl_xor(acc, 2));
+#pragma unroll
+  for (int m = 1; m < LPB; m <<= 1) acc = g1x_add(acc, g1x_shfl_xor(acc, m));
   if (store && sub == 0) buckets[(uint64_t)q * B + (b - 1)] = acc;
 }
 
@@ -577,8 +578,19 @@ int msm_run_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs, uint32_t c) 
   ZK_LAUNCH(ctx, "msm_sort", 32ull * pairs + 4ull * items, k_msm_sort, dim3(nj), dim3(1024), lds, (const MsmJob*)djobs.get(), c, K, idx.get(), off.get());
   ZK_LAUNCH(ctx, "msm_accum", 100ull * items, k_msm_accum, dim3((max_chunks + 63) / 64, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, (const uint32_t*)idx.get(),
             (const uint32_t*)off.get(), buckets.get(), head.get(), tail.get());
-  ZK_LAUNCH(ctx, "msm_combine", 192ull * nj * B, k_msm_combine, dim3((B + 15) / 16, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, (const uint32_t*)off.get(), buckets.get(),
-            (const G1X*)head.get(), (const G1X*)tail.get());
+  {
+    // Full-width scalars: the top window holds 256 - c*(Wmax-1) bits, of which a folded scalar (< 2^254) fills two
+    // fewer; at <= 2 bits of entropy half of an MSM's points share a handful of buckets -> more lanes per bucket.
+    // (Short-scalar batches -- commitments of quantised weights -- keep four lanes: their top window is partial too.)
+    const bool full = c * Wmax >= 254u;
+    const bool hot = !full || 256u - c * (Wmax - 1) <= 4u || chunks > 12ull * nj * B;  // or simply many chunks per bucket
+    if (hot)
+      ZK_LAUNCH(ctx, "msm_combine", 192ull * nj * B, k_msm_combine<4>, dim3((B + 15) / 16, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, (const uint32_t*)off.get(),
+                buckets.get(), (const G1X*)head.get(), (const G1X*)tail.get());
+    else
+      ZK_LAUNCH(ctx, "msm_combine", 192ull * nj * B, k_msm_combine<2>, dim3((B + 31) / 32, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, (const uint32_t*)off.get(),
+                buckets.get(), (const G1X*)head.get(), (const G1X*)tail.get());
+  }
   const ReduceShape sh = reduce_shape(c);
   ZK_LAUNCH(ctx, "msm_bucket_reduce", 192ull * nj * B, k_msm_rowcol, dim3((sh.nsums * 4 + 63) / 64, nj), dim3(64), 0, (const G1X*)buckets.get(), c, sh, RC.get());
   ZK_LAUNCH(ctx, "msm_horner", 192ull * nj * sh.nsums, k_msm_weighted, dim3(nj), dim3(64), 0, (const MsmJob*)djobs.get(), (const G1X*)RC.get(), c, sh);
