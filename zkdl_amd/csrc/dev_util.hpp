@@ -32,4 +32,50 @@ __device__ __forceinline__ Fr block_sum_fr(Fr x, Fr* lds) {
   return x;
 }
 
+// three workgroup sums at once (the coefficient triple of a sumcheck round): the three shuffle ladders interleave,
+// and there is ONE LDS stage and two barriers instead of three of each.  `lds` holds 3 * blockDim.x/64 elements.
+// Thread 0 returns the totals in x0, x1, x2.
+__device__ __forceinline__ void block_sum3_fr(Fr& x0, Fr& x1, Fr& x2, Fr* lds) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    Fr y0, y1, y2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      y0.v[i] = __shfl_down(x0.v[i], off, 64);
+      y1.v[i] = __shfl_down(x1.v[i], off, 64);
+      y2.v[i] = __shfl_down(x2.v[i], off, 64);
+    }
+    x0 = fr_add(x0, y0);
+    x1 = fr_add(x1, y1);
+    x2 = fr_add(x2, y2);
+  }
+  if (nw == 1) return;
+  __syncthreads();  // protect lds reuse across consecutive calls
+  if (lane == 0) {
+    lds[3 * wave + 0] = x0;
+    lds[3 * wave + 1] = x1;
+    lds[3 * wave + 2] = x2;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    x0 = lane < nw ? lds[3 * lane + 0] : fr_zero();
+    x1 = lane < nw ? lds[3 * lane + 1] : fr_zero();
+    x2 = lane < nw ? lds[3 * lane + 2] : fr_zero();
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {  // nw <= 16
+      Fr y0, y1, y2;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        y0.v[i] = __shfl_down(x0.v[i], off, 64);
+        y1.v[i] = __shfl_down(x1.v[i], off, 64);
+        y2.v[i] = __shfl_down(x2.v[i], off, 64);
+      }
+      x0 = fr_add(x0, y0);
+      x1 = fr_add(x1, y1);
+      x2 = fr_add(x2, y2);
+    }
+  }
+}
+
 }  // namespace zk

@@ -85,7 +85,7 @@ __device__ __forceinline__ void k_sc_round(uint32_t zk_nblk, const Fr* __restric
                                                    const Fr* __restrict__ fold, ScLevels lv, const Fr* __restrict__ B, uint32_t in_size, uint32_t out_size,
                                                    Fr* __restrict__ partial, const Fr* __restrict__ prev_partial, uint32_t prev_blocks, uint32_t prev_cols,
                                                    Fr* __restrict__ prev_dst) {
-  __shared__ Fr lds[4];
+  __shared__ Fr lds[12];
   constexpr int NE = 1 << R;
   Fr x[R];
 #pragma clang loop unroll(full)
@@ -165,11 +165,15 @@ __device__ __forceinline__ void k_sc_round(uint32_t zk_nblk, const Fr* __restric
   if (fact) sweep(std::true_type{});
   else sweep(std::false_type{});
 #pragma clang loop unroll(full)
-  for (int i = 0; i < 3 * R; i++) {
-    Fr t = block_sum_fr(acc[i], lds);
+  for (int j = 0; j < R; j++) {
+    block_sum3_fr(acc[3 * j], acc[3 * j + 1], acc[3 * j + 2], lds);
     if (threadIdx.x == 0) {
-      if (fact) t = fr_mul(t, B[(blockIdx.x * P) >> lv.c[0]]);
-      partial[(uint64_t)blockIdx.x * (3 * R) + i] = t;
+#pragma clang loop unroll(full)
+      for (int q = 0; q < 3; q++) {
+        Fr t = acc[3 * j + q];
+        if (fact) t = fr_mul(t, B[(blockIdx.x * P) >> lv.c[0]]);
+        partial[(uint64_t)blockIdx.x * (3 * R) + 3 * j + q] = t;
+      }
     }
   }
   // workgroup 0 also closes the previous launch: its partials were completed by the kernel boundary
@@ -194,7 +198,7 @@ __device__ __forceinline__ void k_sc_tail(uint32_t zk_nblk, const Fr* __restrict
   Fr* ta = sm;                                              // SC_TAIL_N
   Fr* tb = sm + SC_TAIL_N;                                  // SC_TAIL_N (unused for SC_BIN)
   Fr* E = sm + (MODE == SC_BIN ? SC_TAIL_N : 2 * SC_TAIL_N);  // SC_TAIL_N / 2 weights
-  Fr* red = E + SC_TAIL_N / 2;                              // 8 reduction slots
+  Fr* red = E + SC_TAIL_N / 2;                              // 24 reduction slots (3 per wave)
   const uint32_t tid = threadIdx.x;
   if (prev_blocks) {
     for (uint32_t q = 0; q < prev_cols; q++) {
@@ -255,9 +259,7 @@ __device__ __forceinline__ void k_sc_tail(uint32_t zk_nblk, const Fr* __restrict
     Fr ne = fr_zero();
     const uint32_t nE = (MODE != SC_IP && r + 1 < k) ? (1u << (k - r - 2)) : 0u;
     if (g < nE) ne = fr_add(E[2 * g], E[2 * g + 1]);
-    s0 = block_sum_fr(s0, red);
-    s1 = block_sum_fr(s1, red);
-    s2 = block_sum_fr(s2, red);
+    block_sum3_fr(s0, s1, s2, red);
     if (tid == 0) {
       proof[3 * r + 0] = s0;
       proof[3 * r + 1] = s1;
@@ -360,7 +362,7 @@ static int run_sumcheck(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n,
     r += R;
     launch++;
   }
-  size_t lds = ((MODE == SC_BIN ? 1 : 2) * SC_TAIL_N + SC_TAIL_N / 2 + 8) * sizeof(Fr);
+  size_t lds = ((MODE == SC_BIN ? 1 : 2) * SC_TAIL_N + SC_TAIL_N / 2 + 24) * sizeof(Fr);
   static bool lds_attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in on some runtimes
   if (!lds_attr_set) {
     zk::Kern<512, &k_sc_tail<MODE>>::set_max_lds(lds);
