@@ -121,7 +121,7 @@ __device__ __forceinline__ void k_binp_prep(uint32_t zk_nblk, const Fr* __restri
 template <int NB, class WordT>
 __device__ __forceinline__ void k_binp_rounds(uint32_t zk_nblk, const WordT* __restrict__ packed, uint32_t n, PackedLayout L, const Fr* __restrict__ tab_g, const Fr* __restrict__ AH,
                                                       const Fr* __restrict__ BH, uint32_t ch, Fr* __restrict__ a3, Fr* __restrict__ partial) {
-  extern __shared__ Fr tab[];  // L.total entries + 8 reduction slots
+  extern __shared__ Fr tab[];  // L.total entries + 16 reduction slots
   Fr* red = tab + L.total;
   for (uint32_t i = threadIdx.x; i < L.total; i += blockDim.x) tab[i] = tab_g[i];
   __syncthreads();
@@ -166,10 +166,13 @@ __device__ __forceinline__ void k_binp_rounds(uint32_t zk_nblk, const WordT* __r
 #pragma unroll
     for (int i = 0; i < 7; i++) acc[i] = fr_add(acc[i], fr_mul(w, f[i]));
   }
+  block_sum3_fr(acc[1], acc[2], acc[3], red);
+  block_sum3_fr(acc[4], acc[5], acc[6], red);
+  Fr s0 = block_sum_fr(acc[0], red);
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x * 7] = s0;
 #pragma unroll
-  for (int i = 0; i < 7; i++) {
-    Fr s = block_sum_fr(acc[i], red);
-    if (threadIdx.x == 0) partial[blockIdx.x * 7 + i] = s;
+    for (int i = 1; i < 7; i++) partial[blockIdx.x * 7 + i] = acc[i];
   }
 }
 // proof[0..8] of the three packed rounds
@@ -196,7 +199,7 @@ __device__ __forceinline__ void k_binp_finish(uint32_t zk_nblk, const Fr* __rest
 template <int NB, class WordT>
 __device__ __forceinline__ void k_binp_partial_me(uint32_t zk_nblk, const WordT* __restrict__ packed, uint32_t n, const Fr* __restrict__ A, const Fr* __restrict__ B, uint32_t c,
                                                           Fr* __restrict__ partial) {
-  __shared__ Fr lds[4];
+  __shared__ Fr lds[12];
   const uint32_t grp = blockIdx.y, mask = (1u << c) - 1u;
   Fr acc[8];
 #pragma unroll
@@ -209,10 +212,13 @@ __device__ __forceinline__ void k_binp_partial_me(uint32_t zk_nblk, const WordT*
     for (int j = 0; j < 8; j++)
       if ((bits >> j) & 1u) acc[j] = fr_add(acc[j], w);
   }
+  block_sum3_fr(acc[0], acc[1], acc[2], lds);
+  block_sum3_fr(acc[3], acc[4], acc[5], lds);
+  Fr z = fr_zero();
+  block_sum3_fr(acc[6], acc[7], z, lds);
+  if (threadIdx.x == 0) {
 #pragma unroll
-  for (int j = 0; j < 8; j++) {
-    Fr s = block_sum_fr(acc[j], lds);
-    if (threadIdx.x == 0) partial[((uint64_t)blockIdx.x * (NB / 8) + grp) * 8 + j] = s;
+    for (int j = 0; j < 8; j++) partial[((uint64_t)blockIdx.x * (NB / 8) + grp) * 8 + j] = acc[j];
   }
 }
 __device__ __forceinline__ void k_binp_partial_me_finish(uint32_t zk_nblk, const Fr* __restrict__ partial, uint32_t nblk, uint32_t nb, Fr* __restrict__ out) {
@@ -249,7 +255,7 @@ int binp_sumcheck_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb, 
   ZK_ALLOC(ctx, a3, Fr, a3n);
   const uint32_t grid = stream_grid(n, 256, 768);
   ZK_ALLOC(ctx, partial, Fr, (size_t)grid * 7);
-  const size_t lds = (size_t)(L.total + 8) * sizeof(Fr);
+  const size_t lds = (size_t)(L.total + 16) * sizeof(Fr);
   static bool attr32 = false, attr16 = false;
   uint64_t bytes = (uint64_t)n * (nb / 8) + 32ull * a3n;
   if (nb == 32) {
