@@ -253,7 +253,7 @@ int binp_sumcheck_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb, 
   ZK_LAUNCHB(ctx, "binp_prep", 32ull * nprep, 256, k_binp_prep, dim3(stream_grid(nprep, 256, 64)), 0, u_d, v_d, k, L, ch, tab.get(), AH.get(), BH.get());
   const uint32_t a3n = n * (nb / 8);
   ZK_ALLOC(ctx, a3, Fr, a3n);
-  const uint32_t grid = stream_grid(n, 256, 768);
+  const uint32_t grid = stream_grid(n, 256, 1536);
   ZK_ALLOC(ctx, partial, Fr, (size_t)grid * 7);
   const size_t lds = (size_t)(L.total + 16) * sizeof(Fr);
   static bool attr32 = false, attr16 = false;

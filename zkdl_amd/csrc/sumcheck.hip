@@ -31,7 +31,7 @@ namespace zk {
 enum { SC_IP = 0, SC_HP = 1, SC_BIN = 2 };
 static constexpr uint32_t SC_TAIL_N = 1024;   // table length handled by the LDS-resident tail kernel
 static constexpr uint32_t SC_TAIL_LOG = 10;
-static constexpr uint32_t SC_MAX_BLOCKS = 1024;
+static constexpr uint32_t SC_MAX_BLOCKS = 512;
 
 __device__ __forceinline__ Fr eq_product(const Fr* __restrict__ u, uint32_t nvars, uint32_t j) {
   Fr one = fr_one(), acc = one;
