@@ -227,6 +227,12 @@ int zk_transcript_digest(zk_transcript* tr, zk_fr* out_h);
  * on the context's stream without a host round trip: ranks all-reduce these lanes with ncclSum on
  * uint64 (exact for < 2^32 ranks), then carry-propagate and reduce mod r locally */
 int zk_transcript_digest_dev(zk_transcript* tr, uint64_t* out8_d);
+/* Serialised transcript (the proof values the reference computes and drops, zkfc.cu:139-144): synchronises and
+ * writes   "ZKDLTR01" | u64 n_fr | u64 n_g1 | n_fr x 32 B (Fr, Montgomery limbs, little endian, as Fr_t)
+ *          | n_g1 x 96 B (affine x, y: Fp Montgomery limbs, little endian; zeros for infinity) | n_g1 x 1 B (infinity flags)
+ * into buf_h (capacity cap bytes); *len receives the size (also when buf_h is NULL or too small: ZK_ERR_ARG then,
+ * so a caller can size the buffer with a first call). */
+int zk_transcript_serialize(zk_transcript* tr, void* buf_h, size_t cap, size_t* len);
 /* Finish the proof ASYNCHRONOUSLY: the deferred MSM batch, the canonicalisation of its outputs and (when
  * out8_d is not NULL) the digest_dev above run on one of the context's G1 streams (zk_transcript_stream
  * tells which), behind the Fr work already enqueued, and the main stream does NOT wait for them.  A caller proving a stream of

@@ -546,3 +546,34 @@ def test_int16_weight_contractions_equal_the_fr_path(zk, oracle):
     assert eq(out[1][0], out[0][0]) and eq(out[1][1], out[0][1]) and eq(out[1][2], out[0][2])
     want_fr = prove_mlp_oracle(oracle, model)[0]
     assert eq(out[1][0], want_fr)
+
+
+def test_transcript_serialisation_round_trip(zk, oracle):
+    """zk_transcript_serialize: header, Fr entries, affine G1 entries and infinity flags equal what read() /
+    read_affine() return, and the bytes do not depend on how the proof was scheduled."""
+    import struct
+    from mlp_util import enqueue_proof, setup_mlp_gpu, synth_mlp
+    from zkdl_amd.capi import MSM_PIPPENGER, Transcript
+    zk.set_msm_mode(MSM_PIPPENGER)
+    model = synth_mlp(oracle, [16, 32, 8], 4, seed=123)
+    st = setup_mlp_gpu(zk, model)
+    blobs = []
+    for batch in (1, 0):
+        zk.set_flag("batch_layers", batch)
+        tr = Transcript(zk)
+        enqueue_proof(st, model["chal"], tr)
+        blob = tr.serialize()
+        fr, _ = tr.read()
+        aff, inf = tr.read_affine()
+        assert blob[:8] == b"ZKDLTR01"
+        n_fr, n_g1 = struct.unpack("<QQ", blob[8:24])
+        assert (n_fr, n_g1) == (fr.shape[0], aff.shape[0])
+        body = np.frombuffer(blob, dtype=np.uint8, offset=24)
+        assert eq(body[:32 * n_fr].view(np.uint32).reshape(-1, 8), fr)
+        g = body[32 * n_fr:32 * n_fr + 96 * n_g1].view(np.uint32).reshape(-1, 24)
+        assert eq(g, np.asarray(aff).reshape(-1, 24))
+        assert eq(body[32 * n_fr + 96 * n_g1:], np.asarray(inf).reshape(-1))
+        assert len(blob) == 24 + 32 * n_fr + 97 * n_g1
+        blobs.append(blob)
+    zk.set_flag("batch_layers", 1)
+    assert blobs[0] == blobs[1]

@@ -33,7 +33,7 @@ zk_set_msm_window zk_set_flag zk_gens_create zk_gens_destroy zk_gens_size zk_gen
 zk_fc_out zk_fc_com_size zk_fc_weights zk_fc_com zk_fc_load_input zk_fc_forward zk_fc_prove zk_relu_create
 zk_relu_destroy zk_relu_forward zk_relu_sign zk_relu_mag_bin zk_relu_rem_bin zk_relu_prove zk_transcript_create
 zk_transcript_destroy zk_transcript_reset zk_transcript_flush zk_transcript_counts zk_transcript_read zk_transcript_read_affine
-zk_transcript_digest zk_transcript_digest_dev zk_transcript_seal zk_transcript_stream""".split()
+zk_transcript_digest zk_transcript_digest_dev zk_transcript_serialize zk_transcript_seal zk_transcript_stream""".split()
 
 
 class ZkError(RuntimeError):
@@ -512,6 +512,14 @@ class Transcript:
     def digest_dev(self, out8_ptr):
         """Digest as 8 uint64 lanes written to device memory at `out8_ptr` (no host sync)."""
         self.zk._chk(self.zk.lib.zk_transcript_digest_dev(self.h, _vp(out8_ptr)))
+
+    def serialize(self):
+        """The transcript as bytes in the library's on-disk format (include/zkdl_amd.h: zk_transcript_serialize)."""
+        n = ctypes.c_size_t(0)
+        self.zk.lib.zk_transcript_serialize(self.h, None, ctypes.c_size_t(0), ctypes.byref(n))
+        buf = (ctypes.c_ubyte * n.value)()
+        self.zk._chk(self.zk.lib.zk_transcript_serialize(self.h, buf, ctypes.c_size_t(n.value), ctypes.byref(n)))
+        return bytes(buf)
 
     def seal(self, out8_ptr=None):
         """Finish the proof on the G1 stream without making the main stream wait (zk_transcript_seal)."""

@@ -808,6 +808,31 @@ int zk_transcript_read_affine(zk_transcript* tr, zk_g1a* g1_h, uint8_t* inf_h, s
   ZK_TRY(zk_memcpy_d2h(ctx, g1_h, aff.get(), tr->n_g1 * sizeof(G1A)));
   return zk_memcpy_d2h(ctx, inf_h, inf.get(), tr->n_g1);
 }
+int zk_transcript_serialize(zk_transcript* tr, void* buf_h, size_t cap, size_t* len) {
+  if (!tr) return ZK_ERR_ARG;
+  zk_ctx* ctx = tr->ctx;
+  CHECK_HOST(ctx, len);
+  ZK_TRY(tr->flush());
+  const size_t need = 8 + 16 + tr->n_fr * sizeof(Fr) + tr->n_g1 * (sizeof(G1A) + 1);
+  *len = need;
+  if (!buf_h || cap < need) return ctx->fail(ZK_ERR_ARG, "transcript buffer too small");
+  uint8_t* p = static_cast<uint8_t*>(buf_h);
+  memcpy(p, "ZKDLTR01", 8);
+  const uint64_t nf = tr->n_fr, ng = tr->n_g1;
+  memcpy(p + 8, &nf, 8);
+  memcpy(p + 16, &ng, 8);
+  p += 24;
+  if (tr->n_fr) ZK_TRY(zk_memcpy_d2h(ctx, p, tr->fr_d, tr->n_fr * sizeof(Fr)));
+  p += tr->n_fr * sizeof(Fr);
+  if (tr->n_g1) {
+    ZK_ALLOC(ctx, aff, G1A, tr->n_g1);
+    ZK_ALLOC(ctx, inf, uint8_t, tr->n_g1);
+    ZK_TRY(g1_to_affine_dev(ctx, tr->g1_d, (uint32_t)tr->n_g1, aff.get(), inf.get()));
+    ZK_TRY(zk_memcpy_d2h(ctx, p, aff.get(), tr->n_g1 * sizeof(G1A)));
+    ZK_TRY(zk_memcpy_d2h(ctx, p + tr->n_g1 * sizeof(G1A), inf.get(), tr->n_g1));
+  }
+  return zk_ctx_sync(ctx);
+}
 int zk_transcript_digest(zk_transcript* tr, zk_fr* out_h) {
   if (!tr) return ZK_ERR_ARG;
   zk_ctx* ctx = tr->ctx;
