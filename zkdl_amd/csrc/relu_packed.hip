@@ -289,7 +289,7 @@ int binp_partial_me_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb
   ZK_ALLOC(ctx, B, Fr, (size_t)1 << (k - c));
   const uint32_t nt = (1u << c) + (1u << (k - c));
   ZK_LAUNCHB(ctx, "binp_prep", 32ull * nt, 256, k_eq_pair_tables, dim3(stream_grid(nt, 256, 64)), 0, u_d, k, c, A.get(), B.get());
-  const uint32_t grid = stream_grid(n, 256, 128);
+  const uint32_t grid = stream_grid(n, 256, 64);
   ZK_ALLOC(ctx, partial, Fr, (size_t)grid * nb);
   if (nb == 32)
     ZK_LAUNCHB(ctx, "binp_partial_me", 4ull * n, 256, (k_binp_partial_me<32, uint32_t>), dim3(grid, 4), 0, (const uint32_t*)packed, n, (const Fr*)A.get(), (const Fr*)B.get(), c,
