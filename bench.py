@@ -238,7 +238,9 @@ def main():
     pipelined = not args.no_pipeline and not args.serial
     if args.serial:
         zk.set_flag("lanes", 0)
-    aggs = [torch.zeros(8, dtype=torch.int64, device="cuda") for _ in range(max(2, args.inflight))]
+    # one digest buffer per (transcript, G1 stream) combination: a buffer is then only ever reused by a proof that runs on
+    # the same G1 stream, i.e. strictly behind the all-reduce that last read it
+    aggs = [torch.zeros(8, dtype=torch.int64, device="cuda") for _ in range(4 * max(2, args.inflight))]
     ext_streams = {}
     torch.cuda.synchronize()
 
