@@ -6,15 +6,22 @@ aggregate over xGMI.
 A "step" is one pass of the reference's timed region (demo.cu:124-138): fcs[L-1].prove, then for
 i = L-2..0 relus[i].prove + fcs[i].prove, over one synthetic batch that is already resident in HBM
 (weights quantised + committed, inference done: all of that is setup in the reference too), plus the
-transcript digest and, for N > 1, its all-reduce.  value = step time / (256 * N) in ms, max over
-ranks, exactly K steps between barriers.
+transcript digest.  For N > 1 every rank proves its own batches; the digests of a rank's K proofs are summed
+on the device and ONE all-reduce of that aggregate (8 x uint64 lanes, RCCL over xGMI) closes the timed region.
+value = step time / (256 * N) in ms, max over ranks, exactly K steps between barriers.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mlp18m_b256|mlp18m_b1|tiny]
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (child
+processes, one per GPU, before this process has touched the GPU) and relays rank 0's JSON line; under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is one of the ranks.
 """
 import argparse
 import gc
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -144,52 +151,119 @@ class Workload:
 
 from zkdl_amd.dist import lanes_to_fr  # noqa: E402
 
+VALU_PEAK_TMACPS = 34.0     # measured v_mad_u64_u32 issue peak, tools/instr_rate.hip: 33.96 T lane-MAC/s (8 waves/SIMD, every CU busy)
+FR_MACS, FP_MACS = 136, 300  # 32x32->64 MACs of one Montgomery product (field.hpp: product scanning incl. the reduction)
 
-def cpu_baseline(zk, wl, max_seconds=60.0):
-    """Time the oracle (CPU restatement of the reference algorithm) on a bounded sample of the same
-    workload: the proving loop of the LAST TWO FC layers + the ReLU between them of the 18M MLP at
-    batch 1 (weight-side work is batch-independent), OpenMP over tensor elements."""
+
+def _rv(rng, n):
+    a = rng.integers(0, 1 << 32, size=(n, 8), dtype=np.uint64).astype(np.uint32)
+    a[:, 7] = (a[:, 7].astype(np.uint64) % 1944954707).astype(np.uint32)
+    return a
+
+
+def cpu_baseline(zk, wl, mode="sample"):
+    """Time the oracle (CPU restatement of the reference algorithm, OpenMP over tensor elements) on the SAME
+    workload at the SAME batch size.  mode "sample": FC[L-1] + ReLU[L-2] + FC[L-2] of the timed loop (demo.cu:124-138),
+    inputs = this workload's own activations / weights / generators / commitments downloaded from the device;
+    the rest of the loop is extrapolated -- FC calls by their G1 scalar-mul count (m + 5 n_gens per layer, SURVEY 8d:
+    the opening dominates and is batch-independent), ReLU calls by their element count.  mode "full": every call."""
     from oracle.oracle_py import Oracle
     orc = Oracle()
     sh = wl.shapes
     L = len(sh)
-    sample_layers = [L - 1, L - 2]
+    B_p = wl.B_p
     rng = np.random.default_rng(5)
+    kb = ceil_log2(B_p)
+    layers = list(range(L)) if mode == "full" else [L - 1, L - 2]
+    relus = list(range(L - 1)) if mode == "full" else [L - 2]
+    t_fc = t_relu = 0.0
     t_start = time.perf_counter()
-    Wq, gens, coms = {}, {}, {}
-    for i in sample_layers:
+    for i in sorted(set(layers), reverse=True):
         s = sh[i]
-        w = rng.uniform(-1.0 / np.sqrt(s["n_in"]), 1.0 / np.sqrt(s["n_in"]), size=(s["n_in"], s["n_out"])).astype(np.float32)
-        Wq[i] = orc.fr_mont(orc.float_to_fr(w, s["in_p"], s["out_p"]))
-        gens[i] = wl.gens[i].points().download()               # inputs only; any points time the same
-        coms[i] = wl.fcs[i].com().download()
-    x = rng.standard_normal((1, sh[L - 2]["n_in"])).astype(np.float32)
-    X = orc.fr_mont(orc.float_to_fr(np.abs(x), 1, sh[L - 2]["in_p"]))
-    Z = orc.fc_forward(X, Wq[L - 2], 1, sh[L - 2]["in_p"], sh[L - 2]["out_p"])
-    A, sign, mag, rem = orc.relu_forward(Z)
-    Y = orc.fr_unmont(orc.fc_forward(A, Wq[L - 1], 1, sh[L - 1]["in_p"], sh[L - 1]["out_p"]))
-    prep = time.perf_counter() - t_start
+        W = wl.fcs[i].weights().download()
+        gens = wl.gens[i].points().download()
+        com = wl.fcs[i].com().download()
+        X = (wl.A[i - 1] if i > 0 else wl.X).download()
+        Z = (wl.Yhat if i == L - 1 else wl.Z[i]).download()
+        t0 = time.perf_counter()
+        orc.fc_prove(X, Z, W, s["in_p"], s["out_p"], gens, com, _rv(rng, kb), _rv(rng, ceil_log2(s["in_p"])), _rv(rng, ceil_log2(s["out_p"])))
+        t_fc += time.perf_counter() - t0
+        del W, gens, com, X
+        if i in relus:
+            A_, sign, mag, rem = orc.relu_forward(Z)            # aux tensors as the reference stores them (untimed: inference)
+            k = ceil_log2(B_p * s["out_p"])
+            t0 = time.perf_counter()
+            orc.relu_prove(Z, A_, sign, mag, rem, *[_rv(rng, n) for n in (k + 5, k + 5, k + 4, k + 4, k, k, k)])
+            t_relu += time.perf_counter() - t0
+            del A_, sign, mag, rem
+    wall = time.perf_counter() - t_start
+    g1_cost = lambda s_: s_["m"] + 5 * s_["n_gens"]
+    fc_scale = sum(g1_cost(s_) for s_ in sh) / sum(g1_cost(sh[i]) for i in layers)
+    relu_scale = sum(B_p * sh[i]["out_p"] for i in range(L - 1)) / max(sum(B_p * sh[i]["out_p"] for i in relus), 1)
+    total_s = t_fc * fc_scale + t_relu * relu_scale
+    what = ("the whole prove loop (%d zkFC::prove + %d zkReLU::prove calls)" % (L, L - 1)) if mode == "full" else \
+           ("zkFC::prove of layers %d,%d + zkReLU::prove of layer %d" % (L - 1, L - 2, L - 2))
+    return {"value": total_s * 1e3 / wl.batch, "unit": "ms/example (batch %d)" % wl.batch, "cores": orc.num_threads(), "kind": "port",
+            "sample": "oracle (CPU restatement of the reference algorithm) on %s of this workload at batch %d: FC %.1f s + ReLU %.1f s measured "
+                      "(%.0f s wall incl. downloads and the untimed aux-tensor pass); %s; the reference's CUDA binary cannot run here (no NVIDIA device)"
+                      % (what, wl.batch, t_fc, t_relu, wall,
+                         "nothing extrapolated" if mode == "full" else "extrapolated to all %d + %d calls: FC x%.2f by G1 scalar-mul count, ReLU x%.2f by element count" % (L, L - 1, fc_scale, relu_scale)),
+            "ms_per_proof": total_s * 1e3, "measured_fc_s": t_fc, "measured_relu_s": t_relu, "extrapolated": mode != "full"}
 
-    def rv(n):
-        a = rng.integers(0, 1 << 32, size=(n, 8), dtype=np.uint64).astype(np.uint32)
-        a[:, 7] = (a[:, 7].astype(np.uint64) % 1944954707).astype(np.uint32)
-        return a
 
-    t0 = time.perf_counter()
-    s = sh[L - 1]
-    orc.fc_prove(A, Y, Wq[L - 1], s["in_p"], s["out_p"], gens[L - 1], coms[L - 1], rv(0), rv(ceil_log2(s["in_p"])), rv(ceil_log2(s["out_p"])))
-    k = ceil_log2(sh[L - 2]["out_p"])
-    orc.relu_prove(Z, A, sign, mag, rem, rv(k + 5), rv(k + 5), rv(k + 4), rv(k + 4), rv(k), rv(k), rv(k))
-    s = sh[L - 2]
-    orc.fc_prove(X, Z, Wq[L - 2], s["in_p"], s["out_p"], gens[L - 2], coms[L - 2], rv(0), rv(ceil_log2(s["in_p"])), rv(ceil_log2(s["out_p"])))
-    dt = time.perf_counter() - t0
-    sample_w = sum(sh[i]["in_p"] * sh[i]["out_p"] for i in sample_layers)
-    total_w = sum(s_["in_p"] * s_["out_p"] for s_ in sh)
-    return {"value": dt * 1e3 * total_w / sample_w, "unit": "ms/example (batch 1, extrapolated to 8 layers by padded weight count)",
-            "cores": orc.num_threads(), "kind": "port",
-            "sample": "oracle prove loop of FC[7] + ReLU[6] + FC[6] of the 18M MLP at batch 1: %.1f s measured (prep %.1f s untimed); "
-                      "the reference's CUDA binary cannot run here (no NVIDIA device)" % (dt, prep),
-            "measured_sample_ms": dt * 1e3}
+def msm_fullwidth_probe(zk, log_pairs=24):
+    """G1 MSM Mop/s (BASELINE.json metric, second half): q independent MSMs over 2048 generators with FULL-WIDTH
+    (255-bit, uniform) scalars, q * 2048 = 2^log_pairs (point, scalar) pairs, through zk_msm_batch; HIP-event timed."""
+    from oracle_free_gen import generator_jac
+    n = 2048
+    q = (1 << log_pairs) // n
+    g = zk.gens(zk.g1_mul(zk.g1_fill(n, generator_jac()), zk.fr_random(n)))
+    sc = zk.fr_random(n * q)
+    out = zk.msm_batch(g, sc.view(0, n * min(q, 64)))           # builds the window tables, warms the pools
+    zk.sync()
+    zk.timer_start()
+    out = zk.msm_batch(g, sc)
+    ms = zk.timer_stop_ms()
+    del out, sc
+    g.close()
+    return {"pairs": n * q, "n_gens": n, "msms": q, "ms": ms, "mops": n * q / ms / 1e3, "scalars": "uniform 255-bit"}
+
+
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` outside a launcher: start the N ranks as child processes (this process never touches
+    the GPU), relay rank 0's stdout, exit with the first non-zero child status."""
+    import tempfile
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    rc = 0
+    with tempfile.TemporaryFile() as out0:
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out0 if r == 0 else sys.stderr))
+        while any(pr.poll() is None for pr in procs):
+            bad = [pr.returncode for pr in procs if pr.poll() not in (None, 0)]
+            if bad:                                   # a rank died: the others would wait in the rendezvous forever
+                rc = bad[0]
+                for pr in procs:
+                    if pr.poll() is None:
+                        pr.terminate()
+                break
+            time.sleep(0.2)
+        for pr in procs:
+            try:
+                pr.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                pr.kill()
+            if pr.returncode not in (None, 0) and rc == 0:
+                rc = pr.returncode
+        out0.seek(0)
+        sys.stdout.write(out0.read().decode(errors="replace"))
+        sys.stdout.flush()
+    return rc
 
 
 def main():
@@ -200,13 +274,21 @@ def main():
     ap.add_argument("--workload", default="mlp18m_b256", choices=sorted(WORKLOADS))
     ap.add_argument("--msm", default="pippenger", choices=["pippenger", "literal"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "off"], help="oracle timed on a layer subset at the bench's batch size (default), on the whole loop, or not at all")
+    ap.add_argument("--no-msm-probe", action="store_true", help="skip the full-width 2^24-pair zk_msm_batch throughput probe")
     ap.add_argument("--inflight", type=int, default=3, help="transcripts rotated by the pipelined loop (proofs whose G1 phase may still be running)")
     ap.add_argument("--serial", action="store_true", help="no worker streams at all: every launch runs alone (the schedule the roofline durations are measured under)")
     ap.add_argument("--msm-window", type=int, default=0, help="force the Pippenger window width (0 = library default)")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every proof on the main stream (no overlap of proof i's G1 phase with proof i+1's Fr phase)")
     ap.add_argument("--backend", default=os.environ.get("BENCH_BACKEND", "nccl"), help="nccl (= RCCL, default) | gloo (rehearsal on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses device 0")
+    ap.add_argument("--launcher-selftest", type=int, default=None, metavar="FAIL_RANK",
+                    help="CPU-only check of the N-rank launch path (tests/test_dist_aggregate.py): gloo all-reduce of per-rank digests, no GPU work; "
+                         "FAIL_RANK >= 0 makes that rank exit with status 3 before the rendezvous")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -214,8 +296,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE=%d" % (args.gpus, world))
+    if args.launcher_selftest is not None:
+        from zkdl_amd.dist import allreduce_digest, fr_to_lanes
+        if rank == args.launcher_selftest:
+            sys.exit(3)
+        dist.init_process_group("gloo")
+        lanes = torch.tensor(fr_to_lanes(pow(7, rank + 1, R_MOD) * (R_MOD - 1) % R_MOD), dtype=torch.int64)
+        agg = allreduce_digest(lanes)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"selftest": True, "n_gpus": world, "collective_world_size": dist.get_world_size(), "aggregate_fr": hex(agg)}))
+        dist.destroy_process_group()
+        return
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -233,35 +326,28 @@ def main():
     dims, batch = WORKLOADS[args.workload]
     wl = Workload(zk, dims, batch, seed=rank, inflight=args.inflight)
 
-    # The G1 phase of every proof (MSM batch, canonicalisation, digest) and the all-reduce of its digest are
-    # ordered on the library's G1 stream; the Fr phase of the next proof runs beside them on the worker lanes.
+    # The G1 phase of every proof (MSM batch, canonicalisation, digest) is ordered on the library's G1 stream; the Fr
+    # phase of the next proof runs beside it on the worker lanes.  Every proof leaves its digest (8 x uint64 lanes)
+    # in its own row of `rows`; no torch op and no collective runs per proof.  After the K-th proof the rows are
+    # summed on the device and the rank aggregate is all-reduced ONCE (north_star: "an RCCL all-reduce over xGMI only
+    # for the final sumcheck aggregate") -- ranks never couple their step times.
     pipelined = not args.no_pipeline and not args.serial
     if args.serial:
         zk.set_flag("lanes", 0)
-    # one digest buffer per (transcript, G1 stream) combination: a buffer is then only ever reused by a proof that runs on
-    # the same G1 stream, i.e. strictly behind the all-reduce that last read it
-    aggs = [torch.zeros(8, dtype=torch.int64, device="cuda") for _ in range(4 * max(2, args.inflight))]
-    ext_streams = {}
+    nprof = max(1, min(args.steps, 2))
+    rows = torch.zeros((args.steps + 1, 8), dtype=torch.int64, device="cuda")
+    scratch_rows = torch.zeros((max(args.warmup, 1) + 4 * nprof + 8, 8), dtype=torch.int64, device="cuda")
+    rows_base, scratch_base = rows.data_ptr(), scratch_rows.data_ptr()
     torch.cuda.synchronize()
 
-    def ext_stream(ptr):
-        if ptr not in ext_streams:
-            ext_streams[ptr] = torch.cuda.ExternalStream(ptr, device=torch.device("cuda", local_rank))
-        return ext_streams[ptr]
-
-    def step(i):
+    def step(i, row_ptr):
         chal = wl.challenges(i)
         tr = wl.trs[i % len(wl.trs)] if pipelined else wl.tr
-        agg = aggs[i % len(aggs)]
         wl.prove(chal, tr)
         if pipelined:
-            tr.seal(agg.data_ptr())
+            tr.seal(row_ptr)
         else:
-            tr.digest_dev(agg.data_ptr())
-        if world > 1:
-            with torch.cuda.stream(ext_stream(tr.stream() if pipelined else zk.lib.zk_ctx_stream(zk.ctx))):
-                dist.all_reduce(agg, op=dist.ReduceOp.SUM)      # RCCL over xGMI: 8 x uint64 lanes
-        return agg
+            tr.digest_dev(row_ptr)
 
     def barrier():
         zk.sync()
@@ -270,7 +356,9 @@ def main():
             dist.barrier()
 
     for i in range(args.warmup):
-        step(-1 - i)
+        step(-1 - i, scratch_base + 64 * i)
+    if world > 1:                                # warm the communicator outside the timed region
+        dist.all_reduce(scratch_rows[-1], op=dist.ReduceOp.SUM)
     barrier()
     # keep the collector out of the timed region: a generation-2 pass over torch's object graph costs ~40 ms,
     # i.e. several whole proofs (seen as a one-off stall inside pure host code)
@@ -279,15 +367,22 @@ def main():
     gc.disable()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        agg = step(i)
+        step(i, rows_base + 64 * i)
     t_enq = time.perf_counter() - t0          # host time to enqueue K steps (no device wait inside)
+    zk.sync()                                 # all G1 streams joined: every row is final
+    agg = rows[:args.steps].sum(dim=0)        # < K * 2^32 per lane: exact in int64
+    if world > 1:
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)      # RCCL over xGMI: 8 x uint64 lanes, once per run
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    per_rank_ms = [elapsed * 1e3 / max(args.steps, 1)]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank_ms = [float(x.item()) * 1e3 / max(args.steps, 1) for x in allt]
+        elapsed = max(float(x.item()) for x in allt)
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
     value = ms_per_step / (batch * world)
     aggregate = lanes_to_fr(agg.cpu().tolist())
@@ -297,14 +392,15 @@ def main():
     #    roofline can be read from (rocprofv3 of `bench.py --serial` reproduces it);
     #  * concurrent: the timed region's schedule (4 Fr groups + G1 streams overlapping), where a launch's
     #    duration includes the time it shares the chip with others.
-    nprof = max(1, min(args.steps, 2))
+    prof_row = [0]
 
     def profile_pass(serial):
         zk.set_flag("lanes", 0 if serial else 1)
         zk.prof_reset()
         zk.prof_enable(True)
         for i in range(nprof):
-            step(10_000 + i)
+            step(10_000 + i, scratch_base + 64 * (max(args.warmup, 1) + prof_row[0]))
+            prof_row[0] += 1
         zk.sync()
         p = zk.prof_read()
         zk.prof_enable(False)
@@ -317,60 +413,74 @@ def main():
     kernels = {k: {"ms_per_step": v["ms"] / nprof, "share": v["ms"] / total_ms, "launches_per_step": v["launches"] // nprof,
                    "alg_GBps": (v["bytes"] / v["ms"] / 1e6) if v["ms"] > 0 else 0.0,
                    "concurrent_ms_per_step": (prof_conc[k]["ms"] / nprof) if k in prof_conc else None} for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
-    # roofline for the dominant HBM-streaming kernel family of the timed region.  achieved = algorithmic
-    # bytes per launch / average launch duration (HIP events on the launching stream).
-    # family -> substrings that identify its kernel in rocprofv3's names: the batched launch form is
-    # k_many<N, &body, ...>, which rocprofv3 prints mangled (_ZN2zk6k_manyILi256ETnDaXadL_ZNS_10k_sc_roundILi2ELi1EEE...)
-    hbm_families = {"sumcheck_bin_round": ["k_many", "k_sc_roundILi2ELi1E"], "sumcheck_hp_round": ["k_many", "k_sc_roundILi1ELi1E"],
-                    "sumcheck_ip_round": ["k_many", "k_sc_roundILi0ELi1E"], "fr_contract": ["k_many", "k_colsum"],
-                    "binp_rounds": ["k_many", "k_binp_roundsILi32E"], "fr_fold": ["k_many", "k_fr_fold"]}
-    cands = [k for k in kernels if k in hbm_families] or list(kernels)[:1]
-    dom = max(cands, key=lambda k: kernels[k]["ms_per_step"])
-    pv = prof[dom]
-    achieved = pv["bytes"] / pv["ms"] / 1e6 if pv["ms"] > 0 else 0.0
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path):
-        # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/pmc_summary.py);
-        # gfx950 correction: FETCH_SIZE counts half the bytes of a 16-B-per-lane stream (MI355X_MICROARCH.md, HBM)
-        pmc_all = json.load(open(pmc_path))
-        want = hbm_families.get(dom, [])
-        hits = [v for k, v in pmc_all.items() if want and all(w in k for w in want)]
-        if hits:
-            n = sum(h["launches"] for h in hits)
-            traffic = sum((2.0 * h["fetch_kb_per_launch"] + h["write_kb_per_launch"]) * h["launches"] for h in hits) / max(n, 1) * 1024.0
-    roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic, "avg_launch_ms": pv["ms"] / max(pv["launches"], 1), "alg_bytes_per_launch": pv["bytes"] / max(pv["launches"], 1),
-                "launches_per_step": pv["launches"] // nprof, "measured": "standalone launches (worker streams off) after the timed region; rocprofv3 of `bench.py --serial` agrees",
-                "concurrent_avg_launch_ms": (prof_conc[dom]["ms"] / max(prof_conc[dom]["launches"], 1)) if dom in prof_conc else None,
-                "note": "this family is classified HBM-streaming (96*S bytes binary / 192*S ip+hadamard per table) but measures integer-VALU bound: "
-                        "6-7 Fr Montgomery products (136 MACs, ~330 instructions each) per 96 B, instruction-issue saturated in the large rounds; see valu_roofline"}
-    # integer-VALU view of the same kernel and of the G1 (MSM) kernels: 32x32->64 MACs per second against the
-    # measured v_mad_u64_u32 issue rate (tools/instr_rate.hip: 34 T lane-MAC/s at 8 waves/SIMD)
-    FR_MACS, FP_MACS = 136, 300
-    macs = None
-    if dom.startswith("sumcheck_"):
-        per_pair = {"sumcheck_bin_round": 7, "sumcheck_hp_round": 9, "sumcheck_ip_round": 6}[dom] * FR_MACS   # Fr products per pair (6 / 8 in the factored rounds)
-        bytes_per_pair = 96 if dom == "sumcheck_bin_round" else 192
-        macs = pv["bytes"] / bytes_per_pair * per_pair
-    valu = {"kernel": dom, "peak_TMACps": 34.0, "achieved_TMACps": (macs / pv["ms"] / 1e9) if macs else None}
+    # ---- roofline of the dominant kernel family of the timed region.  Every family on this path is wide-integer
+    # modular arithmetic and measures integer-VALU bound (profiles/: SQ counters), so the bound is "valu":
+    #   achieved = ALGORITHMIC 32x32->64 MACs per launch (Montgomery products the kernel's algorithm needs x MACs per
+    #   product) / average launch duration (HIP events on the launching stream, standalone launches)
+    #   peak     = measured v_mad_u64_u32 issue peak (tools/instr_rate.hip)
+    # The HBM view of the same kernel (algorithmic bytes / duration vs 8 TB/s, PMC traffic) is kept under "hbm".
+    # family -> substrings that identify its kernel in rocprofv3's (mangled) names, Fr products per 32-byte element read
+    # family -> (substrings identifying its kernel in rocprofv3's mangled names, algorithmic bytes per work unit, Fr products per unit):
+    #   binary round: unit = a pair, 96 B (two reads + one write), 6 products (a0 w, da w, three coefficients, the fold; 7 when the weight does not factor)
+    #   Hadamard / inner-product round: unit = a pair of both tables, 192 B, 7 / 5 products ; contraction: unit = an element, 32 B, 1 product
+    fam = {"sumcheck_bin_round": (["k_many", "k_sc_roundILi2ELi1E"], 96, 6), "sumcheck_hp_round": (["k_many", "k_sc_roundILi1ELi1E"], 192, 7),
+           "sumcheck_ip_round": (["k_many", "k_sc_roundILi0ELi1E"], 192, 5), "fr_contract": (["k_many", "k_colsum"], 32, 1),
+           "binp_bytes": (["k_many", "k_binp_bytes"], None, None), "binp_rounds": (["k_many", "k_binp_rounds"], None, None), "msm_accum": (["k_msm_accum"], 100, None)}
+    macs_per_launch = {}
+    for k, v in prof.items():
+        if k in fam and fam[k][2] is not None:
+            macs_per_launch[k] = v["bytes"] / max(v["launches"], 1) / fam[k][1] * fam[k][2] * FR_MACS
     if "msm_accum" in prof:
         items = prof["msm_accum"]["bytes"] / 100.0          # ZK_LAUNCH passes 100 B per (pair, window) item
-        valu["msm_accum_TMACps"] = items * 11 * FP_MACS / prof["msm_accum"]["ms"] / 1e9   # 11 Fp products per mixed add
-        valu["msm_pairs_per_s_prove"] = sum(1 for _ in [0]) and (items / 26.0) / (sum(prof[k]["ms"] for k in prof if k.startswith("msm_") or k == "g1_canonicalise") / 1e3)
-    roofline["valu_roofline"] = valu
+        macs_per_launch["msm_accum"] = items * 10 * FP_MACS / max(prof["msm_accum"]["launches"], 1)   # 8M + 2S per XYZZ mixed add
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_r02.json")
+    pmc_all = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
+    cands = [k for k in kernels if k in macs_per_launch] or list(kernels)[:1]
+    dom = max(cands, key=lambda k: kernels[k]["ms_per_step"])
+    pv = prof[dom]
+    avg_ms = pv["ms"] / max(pv["launches"], 1)
+    hbm_achieved = pv["bytes"] / pv["ms"] / 1e6 if pv["ms"] > 0 else 0.0
+    want = fam[dom][0] if dom in fam else [dom]
+    pmc_hit = None
+    for name, rec in pmc_all.get("kernels", {}).items():
+        if all(w in name for w in want):
+            pmc_hit = rec if pmc_hit is None or rec.get("launches", 0) > pmc_hit.get("launches", 0) else pmc_hit
+    traffic = (2.0 * pmc_hit["fetch_kb_per_launch"] + pmc_hit["write_kb_per_launch"]) * 1024.0 if pmc_hit and "fetch_kb_per_launch" in pmc_hit else None
+    achieved = macs_per_launch.get(dom, 0.0) / avg_ms / 1e9 if avg_ms > 0 else 0.0
+    roofline = {"kernel": dom, "bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TMACPS, "unit": "TMAC/s (32x32->64 integer multiply-accumulates per second)",
+                "frac": achieved / VALU_PEAK_TMACPS, "traffic": traffic, "avg_launch_ms": avg_ms, "alg_macs_per_launch": macs_per_launch.get(dom),
+                "launches_per_step": pv["launches"] // nprof,
+                "measured": "standalone launches (worker streams off) after the timed region, HIP events on the launching stream; rocprofv3 of `bench.py --serial` agrees (profiles/)",
+                "concurrent_avg_launch_ms": (prof_conc[dom]["ms"] / max(prof_conc[dom]["launches"], 1)) if dom in prof_conc else None,
+                "hbm": {"achieved": hbm_achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBPS, "alg_bytes_per_launch": pv["bytes"] / max(pv["launches"], 1),
+                        "traffic_bytes_per_launch": traffic},
+                "pmc": {k: pmc_hit[k] for k in pmc_hit if k not in ("fetch_kb_per_launch", "write_kb_per_launch")} if pmc_hit else None,
+                "note": "wide-integer modular arithmetic: no MFMA mapping; HBM traffic (PMC) equals the algorithmic bytes, the SIMDs are instruction-issue bound "
+                        "(profiles/pmc_r02.json: VALU busy); peak = measured issue rate of the MAC instruction, so frac is the share of issue slots doing algorithmic MACs",
+                "other_kernels_TMACps": {k: macs_per_launch[k] / (prof[k]["ms"] / max(prof[k]["launches"], 1)) / 1e9 for k in macs_per_launch if k != dom and prof[k]["ms"] > 0}}
 
     out = {"metric": "proving ms/example (batch 256) on 18M-param MLP", "value": value, "unit": "ms/example", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (Fr) / u32x12 (Fp) limbs",
            "data": "synthetic",
-           "config": {"workload": args.workload, "dims": dims, "batch_per_gpu": batch, "parallelism": "independent proofs per rank, RCCL all-reduce of the aggregate",
+           "config": {"workload": args.workload, "dims": dims, "batch_per_gpu": batch, "parallelism": "independent proofs per rank, one RCCL all-reduce of the run aggregate",
                       "msm": args.msm},
-           "ms_per_proof": ms_per_step, "host_enqueue_ms_per_step": t_enq * 1e3 / max(args.steps, 1), "aggregate_fr": hex(aggregate), "setup": wl.info, "roofline": roofline, "kernels": kernels,
+           "ms_per_proof": ms_per_step, "per_rank_ms_per_proof": per_rank_ms, "collective_world_size": (dist.get_world_size() if world > 1 else 1),
+           "collective_backend": (dist.get_backend() if world > 1 else None),
+           "host_enqueue_ms_per_step": t_enq * 1e3 / max(args.steps, 1), "aggregate_fr": hex(aggregate), "setup": wl.info, "roofline": roofline, "kernels": kernels,
            "g1_msm_mops_commit": wl.info["commit_mops"]}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(zk, wl)
+    if "msm_accum" in prof:
+        g1_ms = sum(prof[k]["ms"] for k in prof if k.startswith("msm_") or k == "g1_canonicalise") / nprof
+        out["g1_msm_mops_prove"] = (prof["msm_accum"]["bytes"] / 100.0 / 26.0 / nprof) / g1_ms / 1e3 if g1_ms > 0 else None   # full-width pairs of one proof / its G1 kernels' time
+    if rank == 0 and not args.no_msm_probe and args.workload.startswith("mlp18m"):
+        out["g1_msm_fullwidth"] = msm_fullwidth_probe(zk)
+        out["g1_msm_mops"] = out["g1_msm_fullwidth"]["mops"]
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_baseline != "off":
+        out["cpu_baseline"] = cpu_baseline(zk, wl, args.cpu_baseline)
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
     zk.close()

@@ -27,8 +27,10 @@
 extern "C" {
 #endif
 
-typedef struct { uint32_t v[8]; } zk_fr;        /* Fr_t          (fr-tensor.cuh:13) */
-typedef struct { uint32_t v[12]; } zk_fp;       /* Fp_t          (g1-tensor.cuh:10) */
+/* The limb array is reachable as .v (this ABI) and as .val (the reference's member name, bls12-381.cuh:120,222),
+ * so reference-style code such as zkrelu.cu:3-9 (`x.val[0]`) compiles against the C++ mirror unchanged. */
+typedef struct { union { uint32_t v[8]; uint32_t val[8]; }; } zk_fr;      /* Fr_t   (fr-tensor.cuh:13) */
+typedef struct { union { uint32_t v[12]; uint32_t val[12]; }; } zk_fp;    /* Fp_t   (g1-tensor.cuh:10) */
 typedef struct { zk_fp x, y; } zk_g1a;          /* G1Affine_t    (fr-tensor.cuh:14) */
 typedef struct { zk_fp x, y, z; } zk_g1j;       /* G1Jacobian_t  (fr-tensor.cuh:15) */
 

@@ -52,3 +52,28 @@ def test_lane_roundtrip_and_carry():
     # lanes that each overflow 32 bits after summation still reduce correctly
     lanes = [0xFFFFFFFF * 7] * 8
     assert lanes_to_fr(lanes) == sum((0xFFFFFFFF * 7) << (32 * j) for j in range(8)) % R_MOD
+
+
+def _run_bench(*argv):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, env=env, timeout=300)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_launches_its_own_ranks(world):
+    """`python bench.py --gpus N` as the driver invokes it (no WORLD_SIZE): the parent spawns N ranks, rank 0's
+    JSON line comes back on stdout, and the ranks see each other (gloo here; the collective path on CPU)."""
+    import json
+    out = _run_bench("--gpus", str(world), "--launcher-selftest", "-1")
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    want = sum(pow(7, r + 1, R_MOD) * (R_MOD - 1) % R_MOD for r in range(world)) % R_MOD
+    assert rec["n_gpus"] == world and rec["collective_world_size"] == world and int(rec["aggregate_fr"], 16) == want
+
+
+def test_bench_launcher_propagates_a_dead_rank():
+    out = _run_bench("--gpus", "2", "--launcher-selftest", "1")
+    assert out.returncode == 3

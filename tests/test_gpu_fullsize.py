@@ -174,6 +174,55 @@ def check_workload(zk, wl, relu_layers, fc_layers):
     return fr, aff, inf
 
 
+def g1_ints(aff, inf):
+    return [bm.affine_mont_to_int(a, bool(i)) for a, i in zip(aff, inf)]
+
+
+def check_opening_points(zk, wl, layer, seed):
+    """Full-size G1 values, checked three ways for one layer of the workload (2048 generators, c = 10, 26 windows,
+    buckets stitched across many chunks -- the regime that exists only at this size):
+      1. zk_open under ZK_MSM_LITERAL -- the reference's op sequence (commitment.cu:43-92), whose Jacobian limbs are
+         bit-identical to the oracle at small sizes -- against zk_open under ZK_MSM_PIPPENGER (bucket MSMs over the
+         flattened opening): all 3k+2 points must be the same group elements (affine-canonical form);
+      2. the me_open round relation of SURVEY.md App. E evaluated by the big-integer model on those points:
+         T_{r+1} = u(1-u) T_r + (1-u)^2 T0_r + u^2 T1_r  (u = unmont(challenge)), because T_r is the commitment of the
+         round's scalars under the round's generators; and at the end  T_last' = proof.back() * t(0);
+      3. binding to the layer commitment: T_0 = [R mod r] * com(u_hi), com(u_hi) the first transcript point."""
+    from zkdl_amd.capi import MSM_LITERAL, MSM_PIPPENGER
+    rng = np.random.default_rng(seed)
+    s = wl.shapes[layer]
+    gens, fc = wl.gens[layer], wl.fcs[layer]
+    import bench
+    k = bench.ceil_log2(s["in_p"]) + bench.ceil_log2(s["out_p"])
+    k_lo = bench.ceil_log2(s["n_gens"])
+    u = np.zeros((k, 8), np.uint32)
+    u[:] = rng.integers(0, 1 << 32, size=(k, 8), dtype=np.uint64).astype(np.uint32)
+    u[:, 7] = (u[:, 7].astype(np.uint64) % 1944954707).astype(np.uint32)
+    res = {}
+    for mode in (MSM_LITERAL, MSM_PIPPENGER):
+        zk.set_msm_mode(mode)
+        ret, ce, proof = zk.open(gens, fc.weights(), fc.com(), u)
+        pts = zk.upload(np.concatenate([ce.reshape(1, 36), proof]))
+        aff, inf = zk.g1_to_affine(pts)
+        res[mode] = (ret, aff, inf)
+    zk.set_msm_mode(MSM_PIPPENGER)
+    assert eq(res[MSM_LITERAL][0], res[MSM_PIPPENGER][0])
+    assert eq(res[MSM_LITERAL][1], res[MSM_PIPPENGER][1]) and eq(res[MSM_LITERAL][2], res[MSM_PIPPENGER][2])
+    ret, aff, inf = res[MSM_PIPPENGER]
+    assert aff.shape[0] == 3 * k_lo + 2
+    P = g1_ints(aff, inf)
+    com_eval, proof = P[0], P[1:]
+    uh = ints(u[:k_lo])                                 # generator-side challenges, un-Montgomery'd
+    for r in range(k_lo):
+        T, T0, T1 = proof[3 * r:3 * r + 3]
+        nxt = bm.g1_add(bm.g1_add(bm.g1_mul(T, uh[r] * (1 - uh[r]) % R), bm.g1_mul(T0, (1 - uh[r]) ** 2 % R)), bm.g1_mul(T1, uh[r] ** 2 % R))
+        want = proof[3 * (r + 1)] if r + 1 < k_lo else bm.g1_mul(proof[3 * k_lo], bm.limbs_to_int(ret))   # raw (Montgomery-form) limbs of t(0)
+        assert nxt == want, ("me_open round", r)
+    assert proof[0] == bm.g1_mul(com_eval, bm.RR % R), "T_0 must commit to the row-folded weights"
+    # com(u_hi) itself: the commitment points' multilinear evaluation at the row challenges, against the literal G1_me
+    assert com_eval == bm.jac_to_affine_int(zk.g1_me(fc.com(), u[k_lo:]))
+
+
 def test_mlp18m_batch256_verifies(zk):
     """BASELINE configs[2]: every layer of the 18M-parameter MLP at batch 256."""
     import bench
@@ -181,6 +230,19 @@ def test_mlp18m_batch256_verifies(zk):
     wl = bench.Workload(zk, dims, batch, seed=5)
     L = len(wl.shapes)
     check_workload(zk, wl, relu_layers=set(range(L - 1)), fc_layers=set(range(L)))
+    check_opening_points(zk, wl, layer=3, seed=77)      # 2048 x 2048 weights, 2048 generators, 2048 commitment rows
+    check_opening_points(zk, wl, layer=0, seed=78)      # 1024 x 1024, 1024 generators
+
+
+def test_mlp18m_batch1_verifies(zk):
+    """BASELINE configs[1]: the same model at batch 1 (k_bs = 0: `partial_me` with no challenges is the identity,
+    fr-tensor.cu:370-374; every activation table is one row)."""
+    import bench
+    dims, batch = bench.WORKLOADS["mlp18m_b1"]
+    wl = bench.Workload(zk, dims, batch, seed=6)
+    L = len(wl.shapes)
+    check_workload(zk, wl, relu_layers=set(range(L - 1)), fc_layers=set(range(L)))
+    check_opening_points(zk, wl, layer=L - 1, seed=79)  # 2048 x 1024, 2048 generators, 1024 commitment rows
 
 
 def test_deep4096_slice_verifies_and_2p24_commit_is_linear(zk):

@@ -30,7 +30,7 @@ def test_demo_driver_matches_float_model_and_oracle(tmp_path, oracle):
     import bigint_model as bm
     d = str(tmp_path)
     subprocess.run([sys.executable, "-m", "zkdl_amd.model", "--dims", "6,5,4", "--batch", "3", "--seed", "7", "--out-dir", d], check=True, cwd=ROOT)
-    run = subprocess.run([exe, os.path.join(d, "traced_model.pt"), os.path.join(d, "sample_input.pt"), "--seed", "5"], capture_output=True, text=True, cwd=d, timeout=600)
+    run = subprocess.run([exe, os.path.join(d, "traced_model.pt"), os.path.join(d, "sample_input.pt"), "--seed", "5", "--dump", d], capture_output=True, text=True, cwd=d, timeout=600)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "Total number of parameters: 50" in run.stdout and "seconds per data point." in run.stdout
     lines = open(os.path.join(d, "demo.out")).read().strip().strip("[]").split("\n")
@@ -51,3 +51,48 @@ def test_demo_driver_matches_float_model_and_oracle(tmp_path, oracle):
     A, *_ = oracle.relu_forward(oracle.fc_forward(X, Wq[0], 4, 8, 8))
     Y = oracle.fr_unmont(oracle.fc_forward(A, Wq[1], 4, 8, 4))
     assert vals == [bm.limbs_to_int(r) for r in Y]
+
+    # the proof itself: replay the demo's generators and challenges (--dump) through the oracle and compare the
+    # serialised transcript -- every Fr value bit for bit, every G1 value in affine-canonical form
+    from mlp_util import ceil_log2, layer_shapes, prove_mlp_oracle
+    dims, batch = [6, 5, 4], 3
+    shapes = layer_shapes(dims)
+    gens = [np.fromfile(os.path.join(d, "gens_%d.bin" % i), dtype=np.uint32).reshape(-1, 36) for i in range(len(shapes))]
+    assert [g.shape[0] for g in gens] == [s["n_gens"] for s in shapes]
+    ch = np.fromfile(os.path.join(d, "challenges.bin"), dtype=np.uint32).reshape(-1, 8)
+    pos = [0]
+
+    def take(n):
+        out = ch[pos[0]:pos[0] + n]
+        pos[0] += n
+        return out
+
+    B_p, L = 1 << ceil_log2(batch), len(shapes)
+
+    def fc_ch(s):
+        return [take(ceil_log2(B_p)), take(ceil_log2(s["in_p"])), take(ceil_log2(s["out_p"]))]
+
+    def relu_ch(s):
+        k = ceil_log2(B_p * s["out_p"])
+        return [take(n) for n in (k + 5, k + 5, k + 4, k + 4, k, k, k)]
+
+    chal = [("fc", L - 1, fc_ch(shapes[L - 1]))]
+    for i in range(L - 2, -1, -1):
+        chal.append(("relu", i, relu_ch(shapes[i])))
+        chal.append(("fc", i, fc_ch(shapes[i])))
+    assert pos[0] == ch.shape[0]
+    model = dict(dims=dims, batch=batch, B_p=B_p, shapes=shapes, W=[w.astype(np.float32) for w in W], X=x.astype(np.float32), gens=gens, chal=chal)
+    fr_o, g1_o = prove_mlp_oracle(oracle, model)
+    aff_o, inf_o = oracle.g1_to_affine(g1_o)
+    blob = open(os.path.join(d, "transcript.bin"), "rb").read()
+    assert blob[:8] == b"ZKDLTR01"
+    n_fr, n_g1 = int.from_bytes(blob[8:16], "little"), int.from_bytes(blob[16:24], "little")
+    assert (n_fr, n_g1) == (fr_o.shape[0], g1_o.shape[0])
+    off = 24
+    fr_d = np.frombuffer(blob[off:off + 32 * n_fr], dtype=np.uint32).reshape(-1, 8)
+    off += 32 * n_fr
+    aff_d = np.frombuffer(blob[off:off + 96 * n_g1], dtype=np.uint32).reshape(-1, 24)
+    off += 96 * n_g1
+    inf_d = np.frombuffer(blob[off:off + n_g1], dtype=np.uint8)
+    assert np.array_equal(fr_d, fr_o)
+    assert np.array_equal(inf_d, inf_o) and np.array_equal(aff_d, aff_o)

@@ -368,7 +368,8 @@ def test_msm_window_sweep_gives_same_points(zk, oracle, rng, window):
         zk.set_msm_window(0)
 
 
-@pytest.mark.parametrize("dims,batch", [([6, 5, 4], 3), ([16, 32, 8], 4)])
+# batch 1 (BASELINE configs[1]): k_bs = 0, partial_me with no challenges is the identity (fr-tensor.cu:370-374, App. D-3)
+@pytest.mark.parametrize("dims,batch", [([6, 5, 4], 3), ([16, 32, 8], 4), ([5, 3], 1), ([12, 20, 9, 7], 1)])
 def test_mlp_prove_pippenger_matches_oracle(zk, oracle, dims, batch):
     from mlp_util import prove_mlp_gpu, prove_mlp_oracle, synth_mlp
     from zkdl_amd.capi import MSM_PIPPENGER

@@ -1,19 +1,28 @@
 #!/bin/bash
-# Run on the GPU box from the repo root: bench line + rocprofv3 summaries that DESIGN.md / bench.py cite.
-# usage: tools/collect_profiles.sh <tag>      (outputs under gpurun_out/prof_<tag>/, copied into profiles/ by hand)
+# Run on the GPU box from the repo root: the bench line + the rocprofv3 summaries that DESIGN.md / bench.py cite.
+# usage: tools/collect_profiles.sh <tag>   (outputs under gpurun_out/prof_<tag>/; tools/pmc_summary.py condenses the
+# counter CSVs into profiles/pmc_<round>.json, the kernel-stats CSVs are copied into profiles/ by hand)
+# Every rocprofv3 pass runs the program directly after `--` (no env / bash -c hop) and uses --pmc ALONE.
 set -e
-tag=${1:-r01}
+tag=${1:-r02}
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-timeout -k 10 400 python3 bench.py > $out/bench.json 2> $out/bench.err
+B="python3 bench.py --no-cpu-baseline --no-msm-probe"
+timeout -k 10 500 python3 bench.py > $out/bench.json 2> $out/bench.err
 echo "bench done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_serial -o kt -- python3 bench.py --serial --steps 5 --warmup 2 --no-cpu-baseline > $out/kt_serial.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_serial -o kt -- $B --serial --steps 5 --warmup 2 > $out/kt_serial.log 2>&1
 echo "kernel trace (serial) done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_conc -o kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/kt_conc.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_conc -o kt -- $B --steps 5 --warmup 2 > $out/kt_conc.log 2>&1
 echo "kernel trace (concurrent) done"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_rd -o pmc -- python3 bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_rd.log 2>&1
-echo "pmc fetch done"
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_wr -o pmc -- python3 bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_wr.log 2>&1
-echo "pmc write done"
-find $out -name "*.csv" | head -20
+pass() {  # name, counters...
+  name=$1; shift
+  timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $out/pmc_$name -o pmc -- $B --serial --steps 2 --warmup 1 > $out/pmc_$name.log 2>&1 || echo "pmc pass $name FAILED (see $out/pmc_$name.log)"
+  echo "pmc $name done"
+}
+pass rd FETCH_SIZE
+pass wr WRITE_SIZE
+# instruction-issue view (SQ block has 8 slots, GRBM 2): how busy the vector ALUs are while the kernel runs
+pass valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE
+pass lds SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
+find $out -name "*.csv" | head -40

@@ -480,7 +480,7 @@ class Transcript:
         self.h = h
 
     def reset(self):
-        self.zk.lib.zk_transcript_reset(self.h)
+        self.zk._chk(self.zk.lib.zk_transcript_reset(self.h))
 
     def flush(self):
         self.zk._chk(self.zk.lib.zk_transcript_flush(self.h))

@@ -45,12 +45,12 @@ void* zk_ctx::stage_put(const void* src, size_t bytes) {
   // The ring is cut into STAGE_SEGS segments.  Leaving a segment records an event on every stream that can
   // have consumed it (main + lanes); re-entering it STAGE_SEGS-1 segments later waits on those events, which
   // by then have long completed, so steady-state proving never blocks the host here.
-  size_t need = (bytes + 63) & ~(size_t)63;
-  const size_t seg_size = stage_cap / STAGE_SEGS;
-  if (need > seg_size) return nullptr;
-  size_t seg = stage_off / seg_size;
-  if (stage_off + need > (seg + 1) * seg_size) {
-    auto& evs = stage_events[seg];
+  const size_t need = (bytes + 63) & ~(size_t)63;
+  size_t at = 0, left = 0;
+  bool rolled = false;
+  if (!stage_ring.place(need, &at, &rolled, &left)) return nullptr;
+  if (rolled) {
+    auto& evs = stage_events[left];
     size_t e = 0;
     auto mark = [&](hipStream_t st) {
       if (e == evs.size()) {
@@ -65,16 +65,14 @@ void* zk_ctx::stage_put(const void* src, size_t bytes) {
       if (!mark(l.stream)) return nullptr;
     for (auto& g : g1_lanes)
       if (!mark(g.stream)) return nullptr;
-    stage_marked[seg] = e;
-    seg = (seg + 1) % STAGE_SEGS;
+    stage_marked[left] = e;
+    const size_t seg = stage_ring.seg;
     for (size_t q = 0; q < stage_marked[seg]; q++)
       if (hipEventSynchronize(stage_events[seg][q]) != hipSuccess) return nullptr;
     stage_marked[seg] = 0;
-    stage_off = seg * seg_size;
   }
-  void* dst = stage + stage_off;
+  void* dst = stage + at;
   memcpy(dst, src, bytes);
-  stage_off += need;
   return dst;
 }
 
@@ -183,8 +181,9 @@ int zk_ctx_create(int device, zk_ctx** out) {
       }
     }
   }
-  ctx->stage_cap = 16u << 20;
-  if (hipHostMalloc((void**)&ctx->stage, ctx->stage_cap, hipHostMallocDefault) != hipSuccess) {
+  ctx->stage_ring.cap = 16u << 20;
+  ctx->stage_ring.segs = zk_ctx::STAGE_SEGS;
+  if (hipHostMalloc((void**)&ctx->stage, ctx->stage_ring.cap, hipHostMallocDefault) != hipSuccess) {
     delete ctx;
     return ZK_ERR_ALLOC;
   }
@@ -761,7 +760,9 @@ int zk_transcript_reset(zk_transcript* tr) {
   if (!tr) return ZK_ERR_ARG;
   int rc = ZK_OK;
   tr->unseal();                                // a sealed G1 phase may still be reading the buffers
-  if (!tr->queue.jobs.empty()) rc = tr->flush();  // pending MSMs own scratch that must be released in stream order
+  // pending MSMs own scratch that must be released in stream order, and recorded-but-unexecuted chains (LITERAL
+  // back end, ReLU-only proofs: no MSM jobs) would otherwise be zipped into the next proof's launches
+  if (!tr->queue.jobs.empty() || !tr->rec.empty()) rc = tr->flush();
   tr->n_fr = tr->n_g1 = tr->n_g1_final = 0;
   return rc;
 }

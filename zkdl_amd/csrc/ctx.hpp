@@ -12,6 +12,7 @@
 #include <stdio.h>
 
 #include <map>
+#include <set>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -19,6 +20,7 @@
 #include "../../include/zkdl_amd.h"
 #include "field.hpp"
 #include "g1.hpp"
+#include "stage_ring.hpp"
 
 struct zk_prof_entry {
   const char* name;
@@ -59,7 +61,7 @@ struct zk_ctx {
   // pinned staging ring for small host->device uploads (challenge vectors, broadcast scalars):
   // the caller's host buffer may die right after the call returns, the staged copy may not
   uint8_t* stage = nullptr;
-  size_t stage_cap = 0, stage_off = 0;
+  zk::StageRing stage_ring;  // offsets + current segment (stage_ring.hpp)
   static constexpr size_t STAGE_SEGS = 8;
   std::vector<hipEvent_t> stage_events[STAGE_SEGS];
   size_t stage_marked[STAGE_SEGS] = {};
@@ -198,6 +200,9 @@ struct zk_ctx {
   // of being enqueued, temporaries are kept alive, and small host uploads go into the recorder's blob.
   // `pending` lists the recorders that hold unexecuted chains; settle() runs them (then joins the lanes)
   // so that every other entry point observes plain stream order.
+  // kernels that opted in to > 64 KiB of dynamic LDS on THIS context's device (the attribute is per device)
+  std::set<const void*> lds_opted;
+  bool lds_first_use(const void* key) { return lds_opted.insert(key).second; }
   zk::Recorder* rec = nullptr;
   std::vector<zk::Recorder*> pending_recs;
   bool batch_layers = true;

@@ -94,6 +94,7 @@ enum { REC_GROUP_FC_A = 0, REC_GROUP_FC_OPEN = 1, REC_GROUP_RELU_MAG = 2, REC_GR
 int rec_begin_chain(zk_ctx* ctx, Recorder* r, uint32_t group = 0);  // sets ctx->rec; allocates the blob on first use
 void rec_split(zk_ctx* ctx, uint32_t group);              // recording: what follows is independent of what came before
 void rec_end_chain(zk_ctx* ctx);                           // clears ctx->rec
+void rec_rollback(zk_ctx* ctx, Recorder* r, size_t keep_chains);  // a recording prove call failed: drop its chains
 int rec_execute(zk_ctx* ctx, Recorder* r);                 // zip + launch on ctx->stream, release temporaries
 void* rec_blob_put(zk_ctx* ctx, const void* src, size_t bytes);  // -> DEVICE address inside the blob
 int rec_opaque(zk_ctx* ctx, const char* name, uint64_t bytes, std::function<int(hipStream_t)> fn);

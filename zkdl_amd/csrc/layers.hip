@@ -382,9 +382,34 @@ int fc_forward(zk_ctx* ctx, const zk_fc* fc, const Fr* x, uint32_t xn, Fr* z) {
   return ZK_OK;
 }
 
+// A prove call that fails part-way (allocation, launch) must leave the transcript as it found it: the slots it
+// reserved, the chains it recorded and the MSM jobs it queued are dropped again.
+struct ProveGuard {
+  zk_ctx* ctx;
+  zk_transcript* tr;
+  size_t n_fr, n_g1, chains, jobs, keep;
+  ProveGuard(zk_ctx* c, zk_transcript* t) : ctx(c), tr(t), n_fr(t->n_fr), n_g1(t->n_g1), chains(t->rec.chains.size()), jobs(t->queue.jobs.size()), keep(t->queue.keep.size()) {}
+  int finish(int rc) {
+    if (rc == ZK_OK) return rc;
+    rec_rollback(ctx, &tr->rec, chains);
+    if (tr->queue.jobs.size() > jobs) tr->queue.jobs.resize(jobs);
+    while (tr->queue.keep.size() > keep) tr->queue.keep.pop_back();
+    tr->n_fr = n_fr;
+    tr->n_g1 = n_g1;
+    return rc;
+  }
+};
+
+static int fc_prove_body(zk_ctx* ctx, zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint32_t zn, zk_gens* gens,
+                         const zk_fr* u_bs_h, const zk_fr* u_in_h, const zk_fr* u_out_h, zk_transcript* tr);
 // zkFC::prove, zkfc.cu:128-145
 int fc_prove(zk_ctx* ctx, zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint32_t zn, zk_gens* gens,
              const zk_fr* u_bs_h, const zk_fr* u_in_h, const zk_fr* u_out_h, zk_transcript* tr) {
+  ProveGuard guard(ctx, tr);
+  return guard.finish(fc_prove_body(ctx, fc, x, xn, z, zn, gens, u_bs_h, u_in_h, u_out_h, tr));
+}
+static int fc_prove_body(zk_ctx* ctx, zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint32_t zn, zk_gens* gens,
+                         const zk_fr* u_bs_h, const zk_fr* u_in_h, const zk_fr* u_out_h, zk_transcript* tr) {
   const uint32_t n_gens = gens->n;
   if (xn % fc->in != 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions 1");
   const uint32_t batch = xn / fc->in;
@@ -484,9 +509,16 @@ int relu_materialise_bins(zk_ctx* ctx, zk_relu* relu) {
   return ZK_OK;
 }
 
+static int relu_prove_body(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const Fr* z, uint32_t n, const zk_fr* u_z_h, const zk_fr* v_z_h, const zk_fr* u_r_h,
+                           const zk_fr* v_r_h, const zk_fr* u_rec_h, const zk_fr* u_hp_h, const zk_fr* v_hp_h, zk_transcript* tr);
 // zkReLU::prove, zkrelu.cu:79-100 (Q = 32, R = 16)
 int relu_prove(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const Fr* z, uint32_t n, const zk_fr* u_z_h, const zk_fr* v_z_h, const zk_fr* u_r_h,
                const zk_fr* v_r_h, const zk_fr* u_rec_h, const zk_fr* u_hp_h, const zk_fr* v_hp_h, zk_transcript* tr) {
+  ProveGuard guard(ctx, tr);
+  return guard.finish(relu_prove_body(ctx, relu, x, z, n, u_z_h, v_z_h, u_r_h, v_r_h, u_rec_h, u_hp_h, v_hp_h, tr));
+}
+static int relu_prove_body(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const Fr* z, uint32_t n, const zk_fr* u_z_h, const zk_fr* v_z_h, const zk_fr* u_r_h,
+                           const zk_fr* v_r_h, const zk_fr* u_rec_h, const zk_fr* u_hp_h, const zk_fr* v_hp_h, zk_transcript* tr) {
   (void)z;
   if (relu->n != n || n == 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");  // zkrelu.cu:81
   if ((uint64_t)n * 32 > 0xffffffffull) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");

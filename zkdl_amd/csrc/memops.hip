@@ -4,7 +4,7 @@
 // everything that touches device memory is ordered on the context's stream the way kernels are.  So the
 // library issues no copy-engine work: device-to-device copies, fills and the small pinned-host ->
 // device uploads (challenge vectors, MSM job tables) are kernels, and the host-facing transfers
-// (zk_memcpy_h2d / d2h) drain the stream before a synchronous copy.
+// (zk_memcpy_h2d / d2h) are stream-ordered copies on the context's stream followed by a stream wait.
 #include "ctx.hpp"
 
 namespace zk {
@@ -39,19 +39,21 @@ int dev_zero(zk_ctx* ctx, void* dst, size_t bytes) {
   ZK_LAUNCHB(ctx, "copy", bytes, 256, k_zero4, dim3(stream_grid(n)), 0, (uint32_t*)dst, n);
   return ZK_OK;
 }
-// blocking host <-> device transfers: drain the stream first, then a synchronous copy
+// blocking host <-> device transfers, ordered on the context's stream like everything else (never on the legacy
+// NULL stream: the CU-masked G1 streams are "blocking" streams in HIP's sense -- hipExtStreamCreateWithCUMask has
+// no flags argument -- so NULL-stream work would serialise with a sealed proof's G1 phase)
 int host_to_dev(zk_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return ZK_OK;
   ctx->join_lanes();
+  ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ZK_HIP(ctx, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
   return ZK_OK;
 }
 int dev_to_host(zk_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return ZK_OK;
   ctx->join_lanes();
+  ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ZK_HIP(ctx, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
   return ZK_OK;
 }
 

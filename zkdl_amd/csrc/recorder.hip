@@ -30,6 +30,24 @@ void rec_split(zk_ctx* ctx, uint32_t group) {
 
 void rec_end_chain(zk_ctx* ctx) { ctx->rec = nullptr; }
 
+// A prove call failed while recording: forget the chains it added (everything after the first `keep_chains`).
+// Nothing of those chains was launched, so their temporaries could go back at once; they simply stay on the
+// deferred list until the surviving chains run -- unless no chain survives, in which case the recorder is
+// emptied here (rec_execute treats a recorder without chains as "nothing to do").
+void rec_rollback(zk_ctx* ctx, Recorder* r, size_t keep_chains) {
+  if (ctx->rec == r) ctx->rec = nullptr;
+  if (r->chains.size() > keep_chains) r->chains.resize(keep_chains);
+  if (!r->chains.empty()) return;
+  auto it = std::find(ctx->pending_recs.begin(), ctx->pending_recs.end(), r);
+  if (it != ctx->pending_recs.end()) ctx->pending_recs.erase(it);
+  if (r->blob_dev) ctx->pool_release(r->blob_dev);
+  r->blob_dev = nullptr;
+  for (void* p : r->deferred_free) ctx->pool_release(p);
+  r->deferred_free.clear();
+  r->args.clear();
+  r->blob.clear();
+}
+
 // small host data that recorded kernels read: lands in the blob, which is uploaded once before the chains run
 void* rec_blob_put(zk_ctx* ctx, const void* src, size_t bytes) {
   Recorder* r = ctx->rec;

@@ -256,21 +256,18 @@ int binp_sumcheck_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb, 
   const uint32_t grid = stream_grid(n, 256, 1536);
   ZK_ALLOC(ctx, partial, Fr, (size_t)grid * 7);
   const size_t lds = (size_t)(L.total + 16) * sizeof(Fr);
-  static bool attr32 = false, attr16 = false;
   uint64_t bytes = (uint64_t)n * (nb / 8) + 32ull * a3n;
   if (nb == 32) {
-    if (!attr32) {
+    if (ctx->lds_first_use(zk::Kern<256, &k_binp_rounds<32, uint32_t>>::desc())) {
       zk::Kern<256, &k_binp_rounds<32, uint32_t>>::set_max_lds(lds);
       (void)hipGetLastError();
-      attr32 = true;
     }
     ZK_LAUNCHB(ctx, "binp_rounds", bytes, 256, (k_binp_rounds<32, uint32_t>), dim3(grid), lds, (const uint32_t*)packed, n, L, (const Fr*)tab.get(), (const Fr*)AH.get(),
               (const Fr*)BH.get(), ch, a3.get(), partial.get());
   } else {
-    if (!attr16) {
+    if (ctx->lds_first_use(zk::Kern<256, &k_binp_rounds<16, uint16_t>>::desc())) {
       zk::Kern<256, &k_binp_rounds<16, uint16_t>>::set_max_lds(lds);
       (void)hipGetLastError();
-      attr16 = true;
     }
     ZK_LAUNCHB(ctx, "binp_rounds", bytes, 256, (k_binp_rounds<16, uint16_t>), dim3(grid), lds, (const uint16_t*)packed, n, L, (const Fr*)tab.get(), (const Fr*)AH.get(),
               (const Fr*)BH.get(), ch, a3.get(), partial.get());

@@ -363,11 +363,9 @@ static int run_sumcheck(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n,
     launch++;
   }
   size_t lds = ((MODE == SC_BIN ? 1 : 2) * SC_TAIL_N + SC_TAIL_N / 2 + 24) * sizeof(Fr);
-  static bool lds_attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in on some runtimes
-  if (!lds_attr_set) {
+  if (ctx->lds_first_use(zk::Kern<512, &k_sc_tail<MODE>>::desc())) {  // > 64 KiB of dynamic LDS needs the opt-in, per device
     zk::Kern<512, &k_sc_tail<MODE>>::set_max_lds(lds);
     (void)hipGetLastError();
-    lds_attr_set = true;
   }
   const char* ttag = MODE == SC_IP ? "sumcheck_ip_tail" : MODE == SC_HP ? "sumcheck_hp_tail" : "sumcheck_bin_tail";
   ZK_LAUNCHB(ctx, ttag, (two ? 2ull : 1ull) * 32ull * sz, 512, k_sc_tail<MODE>, dim3(1), lds, a, b, sz, fold_d, weight_d, k, nbig, proof_d, prev_partial, prev_blocks, prev_cols, prev_dst);

@@ -1,10 +1,12 @@
 // zkdl_amd/host/demo.cpp -- the reference driver (demo.cu) on the MI355X library.
-//   ./demo traced_model.pt sample_input.pt [--seed S]
+//   ./demo traced_model.pt sample_input.pt [--seed S] [--dump DIR]
 // Same CLI, same inputs (TorchScript nn.Sequential of bias-free Linear + ReLU; a tensor saved as
 // parameter "0" of a scripted empty module, model.py:4-8), same outputs: demo.out (Y_hat, one
 // 0x%064x per line, demo.cu:119-122) and the three stdout lines (demo.cu:92,140-141).
 // Differences: tensors may live on the CPU (the reference hard-fails, demo.cu:79,114); the contiguous
 // weight tensor is kept alive while its pointer is used (the reference dangles, demo.cu:78).
+// --dump DIR additionally writes what a checker needs to replay the proof: gens_<i>.bin (the randomised generators,
+// Jacobian), challenges.bin (every random_vec draw, in order) and transcript.bin (zk_transcript_serialize).
 #include <torch/script.h>
 #include <torch/torch.h>
 
@@ -79,8 +81,13 @@ int main(int argc, char* argv[]) {
     cerr << "usage: demo traced_model.pt sample_input.pt [--seed S]\n";
     return 2;
   }
-  for (int i = 3; i + 1 < argc; i++)
+  string dump_dir;
+  vector<Fr_t> challenges;
+  for (int i = 3; i + 1 < argc; i++) {
     if (string(argv[i]) == "--seed") zkdl::seed(strtoull(argv[i + 1], nullptr, 0));
+    if (string(argv[i]) == "--dump") dump_dir = argv[i + 1];
+  }
+  if (!dump_dir.empty()) zkdl::challenge_log() = &challenges;
   vector<unique_ptr<Commitment>> generators;
   vector<zkFC> fcs = load_model(argv[1], generators);
   vector<zkReLU> relus(fcs.size() - 1);
@@ -119,5 +126,22 @@ int main(int argc, char* argv[]) {
   cout << "Proof time: " << timer.getTotalTime() / batch_size << " seconds per data point." << endl;
   cout << "Current HIP status: " << 0 << endl;
   cout << "Transcript: " << n_fr << " Fr + " << n_g1 << " G1 values, digest " << digest << endl;
+  if (!dump_dir.empty()) {
+    auto put = [&](const string& name, const void* p, size_t bytes) {
+      ofstream f(dump_dir + "/" + name, ios::binary);
+      f.write(static_cast<const char*>(p), (streamsize)bytes);
+    };
+    for (size_t i = 0; i < generators.size(); i++) {
+      vector<G1Jacobian_t> g(generators[i]->size);
+      zkdl::check(zk_memcpy_d2h(zkdl::ctx(), g.data(), generators[i]->data(), g.size() * sizeof(G1Jacobian_t)));
+      put("gens_" + to_string(i) + ".bin", g.data(), g.size() * sizeof(G1Jacobian_t));
+    }
+    put("challenges.bin", challenges.data(), challenges.size() * sizeof(Fr_t));
+    size_t len = 0;
+    zk_transcript_serialize(zkdl::transcript(), nullptr, 0, &len);
+    vector<unsigned char> buf(len);
+    zkdl::check(zk_transcript_serialize(zkdl::transcript(), buf.data(), buf.size(), &len));
+    put("transcript.bin", buf.data(), len);
+  }
   return 0;
 }

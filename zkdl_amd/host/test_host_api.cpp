@@ -33,6 +33,12 @@ int main() {
   ones.mont();
   EXPECT(eq((a * ones)(3), a(3)));                                   // Montgomery 1 is the identity
   EXPECT(eq(ones.unmont().sum(), Fr_t{{n, 0, 0, 0, 0, 0, 0, 0}}));
+  {  // the reference's member name (bls12-381.cuh:120): reference-style code reads .val[]
+    Fr_t s = ones.sum();
+    EXPECT(s.val[0] == n && s.val[7] == 0 && &s.val[3] == &s.v[3]);
+    Fp_t one = G1_ONE;
+    EXPECT(one.val[0] == 196605u && one.val[11] == G1Jacobian_generator.z.val[11]);
+  }
   // sumcheck: round 0 opens the inner product
   auto u = random_vec(10);
   auto pr = inner_product_sumcheck(a, b, u);

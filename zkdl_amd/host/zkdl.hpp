@@ -20,7 +20,7 @@
 
 #include "../../include/zkdl_amd.h"
 
-typedef zk_fr Fr_t;          // val[] is spelled v[] in the C ABI; layout identical (bls12-381.cuh:120)
+typedef zk_fr Fr_t;          // limbs reachable as .val[] (bls12-381.cuh:120) and as .v[] (the C ABI's spelling)
 typedef zk_fp Fp_t;
 typedef zk_g1a G1Affine_t;
 typedef zk_g1j G1Jacobian_t;
@@ -200,10 +200,16 @@ inline std::ostream& operator<<(std::ostream& os, const FrTensor& A) {   // fr-t
 }
 
 // ------------------------------------------------------------------ proof.cuh:13-34
+namespace zkdl {
+// additive: when set, every challenge random_vec hands out is also appended here, in draw order (demo --dump:
+// lets a checker replay the proof with the same challenges; the reference draws them and forgets them, proof.cu:3-11)
+inline std::vector<Fr_t>*& challenge_log() { static std::vector<Fr_t>* p = nullptr; return p; }
+}  // namespace zkdl
 inline std::vector<Fr_t> random_vec(uint len) {
   zkdl::ensure_seeded();
   std::vector<Fr_t> out(len);
   zkdl::check(zk_random_vec(zkdl::ctx(), len, out.data()));
+  if (zkdl::challenge_log()) zkdl::challenge_log()->insert(zkdl::challenge_log()->end(), out.begin(), out.end());
   return out;
 }
 inline uint ceilLog2(uint num) { return zk_ceil_log2(num); }
