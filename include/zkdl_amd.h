@@ -144,6 +144,8 @@ int zk_set_msm_mode(zk_ctx* ctx, int mode);
 int zk_set_msm_window(zk_ctx* ctx, uint32_t window_bits);   /* 0 = automatic */
 /* Scheduling / representation switches, all on by default; none of them changes a transcript value:
  *   "relu_packed"   ReLU aux sumchecks and partial_me read the packed bits instead of the one-Fr-per-bit tensors
+ *   "relu_bytes"    ... and take rounds 0-4 (32-bit words) / 0-3 (16-bit) from weighted byte histograms instead of the
+ *                   three-round lookup-table form
  *   "batch_layers"  zk_fc_prove / zk_relu_prove record their launches; flush/seal runs them batched across layers
  *   "lanes"         worker streams (the recorder's groups, the G1 streams of zk_transcript_seal); off = one stream
  *   "weights_q16"   layers created while set keep an int16 copy of quantised weights (|w| < 2^15) for the

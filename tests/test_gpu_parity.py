@@ -387,12 +387,16 @@ def test_mlp_prove_pippenger_matches_oracle(zk, oracle, dims, batch):
 
 
 # ------------------------------------------------------------------ packed ReLU proofs vs the one-Fr-per-bit path
-@pytest.mark.parametrize("n", [1, 5, 64, 300, 4096])
-def test_relu_prove_packed_equals_unpacked_and_oracle(zk, oracle, rng, n):
+# three forms of the same proof: byte histograms (default), three-round lookup tables, one field element per bit
+@pytest.mark.parametrize("n,spread", [(1, 46), (2, 46), (5, 46), (64, 46), (300, 46), (300, 20), (4096, 46), (20000, 30)])
+def test_relu_prove_packed_equals_unpacked_and_oracle(zk, oracle, rng, n, spread):
     from zkdl_amd.capi import ReLU, Transcript
     import bigint_model as bm
-    vals = rng.integers(-(1 << 46), 1 << 46, size=n).tolist()
+    vals = rng.integers(-(1 << spread), 1 << spread, size=n).tolist()     # spread 20/30: high bytes of the magnitude all zero
     vals[0] = (1 << 47) - 1
+    if n > 4:
+        vals[3] = 0
+        vals[4] = -(1 << 47) + 1
     X = np.stack([bm.fr_to_mont(v % bm.R_MOD) for v in vals])
     relu = ReLU(zk)
     dX = zk.upload(X)
@@ -400,16 +404,19 @@ def test_relu_prove_packed_equals_unpacked_and_oracle(zk, oracle, rng, n):
     k = zk.ceil_log2(n)
     ch = [rand_fr(rng, m) for m in (k + 5, k + 5, k + 4, k + 4, k, k, k)]
     out = {}
-    for packed in (1, 0):
+    for form, (packed, by) in {"bytes": (1, 1), "tables": (1, 0), "bits": (0, 0)}.items():
         zk.set_flag("relu_packed", packed)
+        zk.set_flag("relu_bytes", by)
         tr = Transcript(zk)
         relu.prove(dX, A, ch, tr)
-        out[packed], _ = tr.read()
+        out[form], _ = tr.read()
     zk.set_flag("relu_packed", 1)
-    assert eq(out[1], out[0])
+    zk.set_flag("relu_bytes", 1)
+    assert eq(out["tables"], out["bits"])
+    assert eq(out["bytes"], out["bits"])
     if n <= 300:
         wA, wsign, wmag, wrem = oracle.relu_forward(X)
-        assert eq(out[1], oracle.relu_prove(X, wA, wsign, wmag, wrem, *ch))
+        assert eq(out["bytes"], oracle.relu_prove(X, wA, wsign, wmag, wrem, *ch))
 
 
 def test_lanes_and_deferred_msm_do_not_change_the_transcript(zk, oracle):

@@ -560,6 +560,7 @@ int zk_set_flag(zk_ctx* ctx, const char* name, int value) {
   CHECK_CTX(ctx);
   CHECK_HOST(ctx, name);
   if (!strcmp(name, "relu_packed")) ctx->relu_packed = value != 0;
+  else if (!strcmp(name, "relu_bytes")) ctx->relu_bytes = value != 0;
   else if (!strcmp(name, "lanes")) ctx->lanes_enabled = value != 0;
   else if (!strcmp(name, "batch_layers")) ctx->batch_layers = value != 0;
   else if (!strcmp(name, "weights_q16")) ctx->flag_q16 = value != 0;

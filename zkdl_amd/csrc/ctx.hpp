@@ -45,6 +45,7 @@ struct zk_ctx {
   uint32_t msm_window = 0;
   bool flag_q16 = true;     // keep an int16 copy of quantised weights for the prover's contractions of W
   bool relu_packed = true;  // ReLU aux proofs from packed bits (relu_packed.hip) instead of one-Fr-per-bit tensors
+  bool relu_bytes = true;   // ... through byte histograms (rounds 0-4 / 0-3 without a table) rather than the three-round table form
   // timing
   hipEvent_t t0 = nullptr, t1 = nullptr;
   bool prof_on = false;

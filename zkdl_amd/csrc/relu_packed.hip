@@ -238,12 +238,418 @@ __device__ __forceinline__ void k_eq_pair_tables(uint32_t zk_nblk, const Fr* __r
   }
 }
 
+// ====================================================================================================
+// Byte-histogram form of the packed rounds (default; the table form above stays as the A/B reference).
+//
+// Every coefficient sum of rounds 0..2 -- and c0, p(1) and the squares of round 3 (pairs of bytes) and of round 4
+// (pairs of byte pairs, 32-bit words only) -- has the shape  sum_g w_g * sum_p T_p[byte_p(word_g)]  with
+// w_g = eq(u[log nb:], g): a table lookup per byte position, weighted per word.  Swapping the sums,
+//     sum_g w_g T_p[byte_p(g)] = sum_e T_p[e] * H[p][e],     H[p][e] = sum_{g : byte_p(g) = e} w_g,
+// so ONE weighted histogram over (byte position, byte value) serves all of them, and the per-word work is one
+// product (w_g) plus integer adds: the Montgomery residue of w_g is cut into five 51-bit limbs and added into
+// 64-bit LDS counters with ds_add_u64 (a residue sum is congruent to the residue of the sum; 8192 words per
+// workgroup keep every counter below 2^64).  Zero bytes are skipped: every table vanishes at 0.
+// What is not a function of single bytes are the cross terms of the squares,
+//     X_j(g) = V3[byte_2j(g)] * V3[byte_2j+1(g)]                  (round 3: (a1 - a0)^2; round 4: a0^2, a1^2)
+//     A(g)   = a0(g) * a1(g)                                      (round 4: (a1 - a0)^2)
+// X_j goes through a second histogram keyed by the LOW byte, H'_j[e] = sum_g [byte_2j = e] w_g V3[byte_2j+1]
+// (one product per pair, then sum_e V3[e] H'_j[e]); A is accumulated directly (two products per word).
+// Per 32-bit word: 6 products instead of 7 + 6 * 3.5 (three generic rounds), and the first table written to HBM
+// has ONE element per word (S/32) instead of four (S/8).  16-bit words: 2 products, table of S/16.
+// Each workgroup stores its counters into a slab of its own; k_binb_reduce adds the slabs (64-bit sums with a carry word),
+// k_binb_finish normalises each bin to a field element and contracts it with the per-bin factors k_binb_prep tabulated.
+struct BytesLayout {
+  uint32_t lognb, npos, R;      // byte positions per word; rounds handled here (4 for 16-bit words, 5 for 32-bit)
+  uint32_t nH, nHP, NF;         // histogram bins (npos*256), cross-term bins ((npos/2)*256), factors per bin
+};
+static BytesLayout bytes_layout(uint32_t nb) {
+  BytesLayout L;
+  L.lognb = nb == 32 ? 5 : 4;
+  L.npos = nb / 8;
+  L.R = nb == 32 ? 5 : 4;
+  L.nH = L.npos * 256;
+  L.nHP = (L.npos / 2) * 256;
+  L.NF = nb == 32 ? 13 : 10;
+  return L;
+}
+static constexpr uint32_t BINB_LIMBS_LDS = 5;   // 51-bit limbs in LDS
+static constexpr uint32_t BINB_WORDS_PER_WG = 4096;  // <= 8192: 13 bits of headroom above the 51-bit limbs
+
+// all NF factors of histogram bin (p, e) -- k_binb_finish says how the sums combine into the round coefficients:
+//   f[0]          round 0: sum over the byte's four bit pairs of Elo_0 * (b0 xor b1)                (c2; c0 = 0, c1 = -c2)
+//   f[1..3]       round 1: sum over the two nibbles of Elo_1 * {a0^2 - a0, a1^2 - a1, (a1 - a0)^2}   (c0, p(1), c2)
+//   f[4..6]       round 2: Elo_2[p] * the same three of the byte's nibble pair
+//   f[7..9]       round 3: bytes (2j, 2j+1) pair up: Elo_3[j] * {[p even] (V3^2 - V3), [p odd] (V3^2 - V3), V3^2}
+//   f[10..12]     round 4 (32-bit words): a0 = (1 - v3) V3[b0] + v3 V3[b1], a1 likewise from bytes 2, 3; with c = 1 - v3 or v3:
+//                 {[p < 2] (c^2 V3^2 - c V3), [p >= 2] the same, c^2 V3^2}   (c0, p(1) and the squares, all without cross terms)
+// elo: this job's position weights in LDS: Elo_0[16] | Elo_1[8] | Elo_2[4] | Elo_3[2]; eqv: eq(v[0..3), i) for i < 8
+__device__ __forceinline__ void binb_factors(uint32_t p, uint32_t e, const Fr* __restrict__ elo, const Fr* __restrict__ eqv, const Fr& v0, const Fr& v1, const Fr& v3,
+                                                     uint32_t NF, Fr* __restrict__ f) {
+  const Fr zero = fr_zero(), one = fr_one();
+  {  // round 0
+    Fr acc = zero;
+    const uint32_t x = e ^ (e >> 1);
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++)
+      if ((x >> (2 * i)) & 1u) acc = fr_add(acc, elo[4 * p + i]);
+    f[0] = acc;
+  }
+  {  // round 1: a pair of bit pairs; a bit pair (x0, x1) folds to x0 (1 - v0) + x1 v0
+    Fr c0 = zero, p1 = zero, c2 = zero;
+    const Fr nv0 = fr_sub(one, v0);
+    for (uint32_t i = 0; i < 2; i++) {
+      const uint32_t nib = (e >> (4 * i)) & 15u;
+      if (!nib) continue;
+      auto fold1 = [&](uint32_t bits) { return bits == 0 ? zero : bits == 1 ? nv0 : bits == 2 ? v0 : one; };
+      const Fr a0 = fold1(nib & 3u), a1 = fold1(nib >> 2), w = elo[16 + 2 * p + i], d = fr_sub(a1, a0);
+      c0 = fr_add(c0, fr_mul(w, fr_sub(fr_sqr(a0), a0)));
+      p1 = fr_add(p1, fr_mul(w, fr_sub(fr_sqr(a1), a1)));
+      c2 = fr_add(c2, fr_mul(w, fr_sqr(d)));
+    }
+    f[1] = c0; f[2] = p1; f[3] = c2;
+  }
+  // folds of the nibbles with (v0, v1) and of the byte with (v0, v1, v2): sums of eq weights over the set bits
+  Fr lo4 = zero, hi4 = zero, t = zero;
+  {
+    const Fr nv1 = fr_sub(one, v1);
+    const Fr e4[4] = {fr_mul(fr_sub(one, v0), nv1), fr_mul(v0, nv1), fr_mul(fr_sub(one, v0), v1), fr_mul(v0, v1)};
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+      if ((e >> i) & 1u) lo4 = fr_add(lo4, e4[i]);
+      if ((e >> (4 + i)) & 1u) hi4 = fr_add(hi4, e4[i]);
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < 8; i++)
+      if ((e >> i) & 1u) t = fr_add(t, eqv[i]);
+  }
+  {  // round 2
+    const Fr w = elo[24 + p], d = fr_sub(hi4, lo4);
+    f[4] = fr_mul(w, fr_sub(fr_sqr(lo4), lo4));
+    f[5] = fr_mul(w, fr_sub(fr_sqr(hi4), hi4));
+    f[6] = fr_mul(w, fr_sqr(d));
+  }
+  const Fr sq = fr_sqr(t);
+  {  // round 3
+    const Fr w = elo[28 + (p >> 1)];
+    const Fr q = fr_mul(w, fr_sub(sq, t));
+    f[7] = (p & 1u) ? zero : q;
+    f[8] = (p & 1u) ? q : zero;
+    f[9] = fr_mul(w, sq);
+  }
+  if (NF > 10) {  // round 4
+    const Fr c = (p & 1u) ? v3 : fr_sub(one, v3);
+    const Fr c2sq = fr_mul(fr_sqr(c), sq);
+    const Fr q = fr_sub(c2sq, fr_mul(c, t));
+    f[10] = p < 2 ? q : zero;
+    f[11] = p >= 2 ? q : zero;
+    f[12] = c2sq;
+  }
+}
+
+// tables for k_binb_words ([V3 | VA = (1 - v3) V3 | VB = v3 V3], 768 entries), the two-level word weights and the per-bin
+// factors -- one launch; workgroups [0, nH / 256) do the factors (one bin per lane), the rest everything else
+__device__ __forceinline__ void k_binb_prep(uint32_t zk_nblk, const Fr* __restrict__ u, const Fr* __restrict__ v, uint32_t k, BytesLayout L, uint32_t ch, Fr* __restrict__ tab,
+                                                    Fr* __restrict__ AH, Fr* __restrict__ BH, Fr* __restrict__ fac) {
+  __shared__ Fr elo[30 + 8];
+  const uint32_t nfb = L.nH / 256;  // factor workgroups (blockDim.x = 256)
+  if (threadIdx.x < 38) {           // every workgroup needs eqv; the factor workgroups also the position weights
+    const uint32_t i = threadIdx.x;
+    Fr r;
+    if (i < 16) r = i < L.npos * 4 ? eq_prod(u + 1, L.lognb - 1, i) : fr_zero();
+    else if (i < 24) r = (i - 16) < L.npos * 2 ? eq_prod(u + 2, L.lognb - 2, i - 16) : fr_zero();
+    else if (i < 28) r = (i - 24) < L.npos ? eq_prod(u + 3, L.lognb - 3, i - 24) : fr_zero();
+    else if (i < 30) r = (i - 28) < (L.npos + 1) / 2 ? eq_prod(u + 4, L.lognb - 4, i - 28) : fr_zero();
+    else r = eq_prod(v, 3, i - 30);
+    elo[i] = r;
+  }
+  __syncthreads();
+  if (blockIdx.x < nfb) {
+    const uint32_t bin = blockIdx.x * 256 + threadIdx.x;
+    Fr f[13];
+    binb_factors(bin >> 8, bin & 255u, elo, elo + 30, v[0], v[1], v[3], L.NF, f);
+    for (uint32_t q = 0; q < L.NF; q++) fac[(size_t)bin * L.NF + q] = f[q];
+    return;
+  }
+  const uint32_t nAH = 1u << ch, nBH = 1u << (k - L.lognb - ch);
+  const uint32_t o1 = 768, o2 = o1 + nAH, total = o2 + nBH;
+  for (uint32_t idx = (blockIdx.x - nfb) * blockDim.x + threadIdx.x; idx < total; idx += (zk_nblk - nfb) * blockDim.x) {
+    if (idx < o1) {
+      const uint32_t e = idx & 255u, which = idx >> 8;
+      Fr t = fr_zero();
+#pragma unroll
+      for (uint32_t i = 0; i < 8; i++)
+        if ((e >> i) & 1u) t = fr_add(t, elo[30 + i]);
+      tab[idx] = which == 0 ? t : which == 1 ? fr_mul(fr_sub(fr_one(), v[3]), t) : fr_mul(v[3], t);
+    } else if (idx < o2) {
+      AH[idx - o1] = eq_prod(u + L.lognb, ch, idx - o1);
+    } else {
+      BH[idx - o2] = eq_prod(u + L.lognb + ch, k - L.lognb - ch, idx - o2);
+    }
+  }
+}
+
+// five 51-bit limbs of a 255-bit residue
+__device__ __forceinline__ void binb_limbs51(const Fr& x, unsigned long long* l) {
+  const unsigned long long q0 = (unsigned long long)x.v[0] | ((unsigned long long)x.v[1] << 32), q1 = (unsigned long long)x.v[2] | ((unsigned long long)x.v[3] << 32),
+                           q2 = (unsigned long long)x.v[4] | ((unsigned long long)x.v[5] << 32), q3 = (unsigned long long)x.v[6] | ((unsigned long long)x.v[7] << 32);
+  const unsigned long long M = (1ull << 51) - 1ull;
+  l[0] = q0 & M;
+  l[1] = ((q0 >> 51) | (q1 << 13)) & M;
+  l[2] = ((q1 >> 38) | (q2 << 26)) & M;
+  l[3] = ((q2 >> 25) | (q3 << 39)) & M;
+  l[4] = q3 >> 12;
+}
+__device__ __forceinline__ void binb_hist_add(unsigned long long* __restrict__ bin, const Fr& x) {
+  unsigned long long l[5];
+  binb_limbs51(x, l);
+#pragma unroll
+  for (int j = 0; j < 5; j++) atomicAdd(bin + j, l[j]);   // ds_add_u64, result unused
+}
+
+// The pass over the packed words.  out[g] = the table entry of word g after R folds (all rounds handled here);
+// partialA[blk] = this workgroup's sum of w a0 a1 (32-bit words); slabs[blk] = this workgroup's histogram counters.
+template <int NB, class WordT>
+__device__ __forceinline__ void k_binb_words(uint32_t zk_nblk, const WordT* __restrict__ packed, uint32_t n, const Fr* __restrict__ tab_g, const Fr* __restrict__ AH,
+                                                     const Fr* __restrict__ BH, uint32_t ch, const Fr* __restrict__ v, Fr* __restrict__ out, Fr* __restrict__ partialA,
+                                                     unsigned long long* __restrict__ slabs) {
+  constexpr uint32_t NPOS = NB / 8, NH = NPOS * 256, NHP = (NPOS / 2) * 256, NBINS = NH + NHP;
+  extern __shared__ unsigned long long lds64[];
+  unsigned long long* H = lds64;                                   // NBINS * 5 counters
+  Fr* tab = reinterpret_cast<Fr*>(lds64 + NBINS * BINB_LIMBS_LDS);   // 768 table entries (16-byte aligned: NBINS * 40 B)
+  Fr* red = tab + 768;                                             // 16 reduction slots
+  for (uint32_t i = threadIdx.x; i < NBINS * BINB_LIMBS_LDS; i += blockDim.x) H[i] = 0ull;
+  for (uint32_t i = threadIdx.x; i < 768; i += blockDim.x) tab[i] = tab_g[i];
+  __syncthreads();
+  const Fr* V3 = tab;
+  const Fr* VA = tab + 256;
+  const Fr* VB = tab + 512;
+  const uint32_t mh = (1u << ch) - 1u;
+  Fr accA = fr_zero();
+  Fr v4 = fr_zero();
+  if (NB == 32) v4 = v[4];
+  // a contiguous range of words per workgroup: at most BINB_WORDS_PER_WG (the host sizes the grid), so that no counter overflows
+  const uint32_t per = (n + zk_nblk - 1) / zk_nblk;
+  const uint32_t g_end = min(n, (blockIdx.x + 1) * per);
+  for (uint32_t g = blockIdx.x * per + threadIdx.x; g < g_end; g += blockDim.x) {
+    const uint32_t word = packed[g];
+    if (word == 0u) {
+      out[g] = fr_zero();
+      continue;
+    }
+    const Fr w = fr_mul(AH[g & mh], BH[g >> ch]);
+    {
+      unsigned long long l[5];
+      binb_limbs51(w, l);
+#pragma unroll
+      for (uint32_t p = 0; p < NPOS; p++) {
+        const uint32_t b = (word >> (8 * p)) & 255u;
+        if (b) {
+          unsigned long long* bin = H + (p * 256 + b) * BINB_LIMBS_LDS;
+#pragma unroll
+          for (int j = 0; j < 5; j++) atomicAdd(bin + j, l[j]);
+        }
+      }
+    }
+    const uint32_t b0 = word & 255u, b1 = (word >> 8) & 255u;
+    if (b0 && b1) binb_hist_add(H + (NH + b0) * BINB_LIMBS_LDS, fr_mul(w, V3[b1]));
+    const Fr a0 = fr_add(VA[b0], VB[b1]);
+    if (NB == 32) {
+      const uint32_t b2 = (word >> 16) & 255u, b3 = word >> 24;
+      if (b2 | b3) {
+        if (b2 && b3) binb_hist_add(H + (NH + 256 + b2) * BINB_LIMBS_LDS, fr_mul(w, V3[b3]));
+        const Fr a1 = fr_add(VA[b2], VB[b3]);
+        if (b0 | b1) accA = fr_add(accA, fr_mul(fr_mul(w, a0), a1));
+        out[g] = fr_add(a0, fr_mul(v4, fr_sub(a1, a0)));
+      } else {
+        out[g] = fr_sub(a0, fr_mul(v4, a0));   // a1 = 0
+      }
+    } else {
+      out[g] = a0;
+    }
+  }
+  if (NB == 32) {
+    accA = block_sum_fr(accA, red);
+    if (threadIdx.x == 0) partialA[blockIdx.x] = accA;
+  }
+  __syncthreads();
+  // flush: this workgroup's counters, as they are, into its own slab (plain coalesced stores; k_binb_reduce adds the slabs)
+  unsigned long long* dst = slabs + (size_t)blockIdx.x * NBINS * BINB_LIMBS_LDS;
+  for (uint32_t i = threadIdx.x; i < NBINS * BINB_LIMBS_LDS; i += blockDim.x) dst[i] = H[i];
+}
+
+// sums[i] = (low 64 bits, carries) of sum over the slabs of counter i
+__device__ __forceinline__ void k_binb_reduce(uint32_t zk_nblk, const unsigned long long* __restrict__ slabs, uint32_t nslab, uint32_t ncount, unsigned long long* __restrict__ sums) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ncount; i += zk_nblk * blockDim.x) {
+    unsigned long long lo = 0, hi = 0;
+    for (uint32_t sl = 0; sl < nslab; sl++) {
+      const unsigned long long x = slabs[(size_t)sl * ncount + i];
+      lo += x;
+      hi += lo < x ? 1ull : 0ull;
+    }
+    sums[2 * (size_t)i] = lo;
+    sums[2 * (size_t)i + 1] = hi;
+  }
+}
+
+// sum_j (lo_j + 2^64 hi_j) 2^(51 j)  (five (lo, hi) pairs, hi_j < 2^32)  ->  field element
+__device__ __forceinline__ Fr binb_bin_to_fr(const unsigned long long* __restrict__ pairs) {
+  uint32_t x[11];
+#pragma unroll
+  for (int i = 0; i < 11; i++) x[i] = 0;
+#pragma unroll
+  for (int j = 0; j < (int)BINB_LIMBS_LDS; j++) {
+    const unsigned long long lo = pairs[2 * j], hi = pairs[2 * j + 1];
+    // the 96-bit value hi:lo shifted left by 51 j bits, added into x
+    const int bit = 51 * j, wi = bit >> 5, sh = bit & 31;
+    const uint32_t w0 = (uint32_t)lo, w1 = (uint32_t)(lo >> 32), w2 = (uint32_t)hi;
+    uint32_t add[4];
+    add[0] = w0 << sh;
+    add[1] = sh ? ((w1 << sh) | (w0 >> (32 - sh))) : w1;
+    add[2] = sh ? ((w2 << sh) | (w1 >> (32 - sh))) : w2;
+    add[3] = sh ? (w2 >> (32 - sh)) : 0u;
+    uint32_t cy = 0;
+#pragma unroll
+    for (int t = 0; t < 11; t++) {
+      if (t < wi) continue;
+      const uint32_t a = (t - wi) < 4 ? add[t - wi] : 0u;
+      uint32_t co;
+      x[t] = __builtin_addc(x[t], a, cy, &co);
+      cy = co;
+    }
+  }
+  // x < 2^(204 + 96): lo (256 bits) + hi * 2^256 with hi < 2^44:  lo mod r by conditional subtraction (2^256 < 3 r), hi * R mod r = mont(hi)
+  Fr lo, hi = fr_zero();
+#pragma unroll
+  for (int i = 0; i < 8; i++) lo.v[i] = x[i];
+  hi.v[0] = x[8];
+  hi.v[1] = x[9];
+  lo = f_reduce_once<FrP>(f_reduce_once<FrP>(lo));
+  if ((x[8] | x[9]) == 0u) return lo;
+  return fr_add(lo, fr_mont(hi));
+}
+
+// One workgroup of 1024 lanes (one histogram bin per lane): normalise every bin, contract with the factors, combine into
+// proof[0 .. 3R).
+//   S_q = sum_bins fac[bin][q] * H[bin]      SX_j = sum_e V3[e] * H'_j[e]      A = sum of the workgroups' partialA
+//   round 0: (0, -S_0, S_0)      round 1: c0 = S_1, p1 = S_2, c2 = S_3      round 2: S_4, S_5, S_6
+//   round 3: c0 = S_7, p1 = S_8, c2 = S_9 - 2 sum_j eq(u[4..lognb), j) SX_j
+//   round 4: c0 = S_10 + m SX_0, p1 = S_11 + m SX_1, c2 = S_12 + m (SX_0 + SX_1) - 2 A,   m = 2 (1 - v3) v3
+//   and c1 = p1 - c0 - c2 everywhere
+__device__ __forceinline__ void k_binb_finish(uint32_t zk_nblk, const unsigned long long* __restrict__ sums, const Fr* __restrict__ fac, const Fr* __restrict__ tab,
+                                                      const Fr* __restrict__ partialA, uint32_t nA, BytesLayout L, const Fr* __restrict__ u, const Fr* __restrict__ v,
+                                                      Fr* __restrict__ proof) {
+  __shared__ Fr red[48];
+  __shared__ Fr S[16];
+  const uint32_t tid = threadIdx.x;
+  const bool own = tid < L.nH;      // nH <= blockDim.x = 1024
+  Fr h = fr_zero();
+  if (own) h = binb_bin_to_fr(sums + (size_t)tid * BINB_LIMBS_LDS * 2);
+  const bool live = own && !l_is_zero(h);
+  for (uint32_t q0 = 0; q0 < L.NF; q0 += 3) {
+    Fr a0 = fr_zero(), a1 = fr_zero(), a2 = fr_zero();
+    if (live) {
+      const Fr* f = fac + (size_t)tid * L.NF + q0;
+      a0 = fr_mul(f[0], h);
+      if (q0 + 1 < L.NF) a1 = fr_mul(f[1], h);
+      if (q0 + 2 < L.NF) a2 = fr_mul(f[2], h);
+    }
+    block_sum3_fr(a0, a1, a2, red);
+    if (tid == 0) {
+      S[q0] = a0;
+      S[q0 + 1] = a1;
+      S[q0 + 2] = a2;
+    }
+  }
+  Fr sx0 = fr_zero(), sx1 = fr_zero(), A = fr_zero();
+  if (tid < L.nHP) {
+    const Fr hp = binb_bin_to_fr(sums + (size_t)(L.nH + tid) * BINB_LIMBS_LDS * 2);
+    if (!l_is_zero(hp)) {
+      const Fr t = fr_mul(tab[tid & 255u], hp);
+      if (tid < 256) sx0 = t;
+      else sx1 = t;
+    }
+  }
+  for (uint32_t i = tid; i < nA; i += blockDim.x) A = fr_add(A, partialA[i]);
+  block_sum3_fr(sx0, sx1, A, red);
+  __syncthreads();
+  if (tid == 0) {
+    const Fr zero = fr_zero();
+    auto put = [&](uint32_t r, const Fr& c0, const Fr& p1, const Fr& c2) {
+      proof[3 * r + 0] = c0;
+      proof[3 * r + 1] = fr_sub(fr_sub(p1, c0), c2);
+      proof[3 * r + 2] = c2;
+    };
+    put(0, zero, zero, S[0]);
+    put(1, S[1], S[2], S[3]);
+    put(2, S[4], S[5], S[6]);
+    Fr cross;
+    if (L.lognb == 5) {
+      const Fr u4 = u[4];
+      cross = fr_add(fr_mul(fr_sub(fr_one(), u4), sx0), fr_mul(u4, sx1));
+    } else {
+      cross = sx0;
+    }
+    put(3, S[7], S[8], fr_sub(S[9], fr_dbl(cross)));
+    if (L.lognb == 5) {
+      const Fr m = fr_dbl(fr_mul(fr_sub(fr_one(), v[3]), v[3]));
+      const Fr m0 = fr_mul(m, sx0), m1 = fr_mul(m, sx1);
+      put(4, fr_add(S[10], m0), fr_add(S[11], m1), fr_sub(fr_add(S[12], fr_add(m0, m1)), fr_dbl(A)));
+    }
+  }
+}
+
+int sumcheck_bin_dev(zk_ctx* ctx, const Fr* a, uint32_t n, const Fr* u_d, const Fr* v_d, uint32_t k, Fr* proof_d);
+static int binb_sumcheck_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb, const Fr* u_d, const Fr* v_d, uint32_t k, Fr* proof_d) {
+  const BytesLayout L = bytes_layout(nb);
+  const uint32_t kh = k - L.lognb;
+  const uint32_t ch = kh < 10 ? kh : 10;
+  const uint32_t nbins = L.nH + L.nHP, ncount = nbins * BINB_LIMBS_LDS;
+  ZK_ALLOC(ctx, tab, Fr, 768);
+  ZK_ALLOC(ctx, AH, Fr, (size_t)1 << ch);
+  ZK_ALLOC(ctx, BH, Fr, (size_t)1 << (kh - ch));
+  ZK_ALLOC(ctx, fac, Fr, (size_t)L.nH * L.NF);
+  const uint32_t nrest = 768 + (1u << ch) + (1u << (kh - ch));
+  ZK_LAUNCHB(ctx, "binp_prep", 32ull * (nrest + L.nH * L.NF), 256, k_binb_prep, dim3(L.nH / 256 + stream_grid(nrest, 256, 16)), 0, u_d, v_d, k, L, ch, tab.get(), AH.get(), BH.get(),
+            fac.get());
+  // one workgroup (1024 lanes) per BINB_WORDS_PER_WG words: few enough that no 64-bit counter can overflow, many enough to amortise
+  // the workgroup's histogram set-up and flush
+  const uint32_t grid = (n + BINB_WORDS_PER_WG - 1) / BINB_WORDS_PER_WG;
+  ZK_ALLOC(ctx, out, Fr, n);
+  ZK_ALLOC(ctx, partialA, Fr, grid);
+  ZK_ALLOC(ctx, slabs, unsigned long long, (size_t)grid * ncount);
+  ZK_ALLOC(ctx, sums, unsigned long long, (size_t)ncount * 2);
+  const size_t lds = (size_t)ncount * 8 + (768 + 16) * sizeof(Fr);
+  // algorithmic traffic: the packed words in, one field element per word out
+  const uint64_t bytes = (uint64_t)n * (nb / 8) + 32ull * n;
+  if (nb == 32) {
+    if (ctx->lds_first_use(zk::Kern<1024, &k_binb_words<32, uint32_t>>::desc())) {
+      zk::Kern<1024, &k_binb_words<32, uint32_t>>::set_max_lds(lds);
+      (void)hipGetLastError();
+    }
+    ZK_LAUNCHB(ctx, "binp_words", bytes, 1024, (k_binb_words<32, uint32_t>), dim3(grid), lds, (const uint32_t*)packed, n, (const Fr*)tab.get(), (const Fr*)AH.get(), (const Fr*)BH.get(), ch,
+              v_d, out.get(), partialA.get(), slabs.get());
+  } else {
+    if (ctx->lds_first_use(zk::Kern<1024, &k_binb_words<16, uint16_t>>::desc())) {
+      zk::Kern<1024, &k_binb_words<16, uint16_t>>::set_max_lds(lds);
+      (void)hipGetLastError();
+    }
+    ZK_LAUNCHB(ctx, "binp_words", bytes, 1024, (k_binb_words<16, uint16_t>), dim3(grid), lds, (const uint16_t*)packed, n, (const Fr*)tab.get(), (const Fr*)AH.get(), (const Fr*)BH.get(), ch,
+              v_d, out.get(), partialA.get(), slabs.get());
+  }
+  ZK_LAUNCHB(ctx, "binp_finish", 8ull * grid * ncount, 256, k_binb_reduce, dim3(stream_grid(ncount, 256, 32)), 0, (const unsigned long long*)slabs.get(), grid, ncount, sums.get());
+  ZK_LAUNCHB(ctx, "binp_finish", 16ull * ncount + 32ull * L.nH * L.NF, 1024, k_binb_finish, dim3(1), 0, (const unsigned long long*)sums.get(), (const Fr*)fac.get(),
+            (const Fr*)tab.get(), (const Fr*)partialA.get(), nb == 32 ? grid : 0u, L, u_d, v_d, proof_d);
+  // rounds R .. k-1 and the final a(0): generic path on the table of one element per word
+  return sumcheck_bin_dev(ctx, out.get(), n, u_d + L.R, v_d + L.R, k - L.R, proof_d + 3 * L.R);
+}
+
 // binary_sumcheck(bit tensor of n elements x nb bits, u, v) with k = ceilLog2(n) + log2(nb) challenges each.
 // packed: uint32 words (nb = 32) or uint16 words (nb = 16).  proof_d receives 3k+1 elements.
 int binp_sumcheck_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb, const Fr* u_d, const Fr* v_d, uint32_t k, Fr* proof_d) {
   if (nb != 32 && nb != 16) return ctx->fail(ZK_ERR_ARG, "packed sumcheck: nb must be 16 or 32");
   PackedLayout L = packed_layout(nb);
   if (n == 0 || k != ceil_log2(n) + L.lognb) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
+  if (ctx->relu_bytes) return binb_sumcheck_dev(ctx, packed, n, nb, u_d, v_d, k, proof_d);
   const uint32_t kh = k - L.lognb;
   const uint32_t ch = kh < 10 ? kh : 10;
   ZK_ALLOC(ctx, tab, Fr, L.total);
