@@ -545,7 +545,14 @@ static int relu_prove_body(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const 
   DBuf<Fr> chd;
   ZK_TRY(upload_fr(ctx, chd, ch.data(), tot));
   const Fr* c = chd.get();
-  if (ctx->relu_packed) {
+  if (ctx->relu_packed && ctx->relu_bytes) {
+    // byte-histogram form: one pass over the packed words serves the bit sumcheck's first rounds AND the partial_me
+    ZK_TRY(binb_sumcheck_pme_dev(ctx, relu->mag_packed, n, 32, c + offs[0], c + offs[1], k + 5, out, c + offs[4], out + 3 * (k + 5) + 1));
+    out += 3 * (k + 5) + 1 + 32;
+    rec_split(ctx, REC_GROUP_RELU_REM);
+    ZK_TRY(binb_sumcheck_pme_dev(ctx, relu->rem_packed, n, 16, c + offs[2], c + offs[3], k + 4, out, c + offs[4], out + 3 * (k + 4) + 1));
+    out += 3 * (k + 4) + 1 + 16;
+  } else if (ctx->relu_packed) {
     ZK_TRY(binp_sumcheck_dev(ctx, relu->mag_packed, n, 32, c + offs[0], c + offs[1], k + 5, out));
     out += 3 * (k + 5) + 1;
     rec_split(ctx, REC_GROUP_FC_A);  // the five pieces are independent: separate chains, spread over the groups

@@ -408,11 +408,14 @@ __device__ __forceinline__ void binb_hist_add(unsigned long long* __restrict__ b
 
 // The pass over the packed words.  out[g] = the table entry of word g after R folds (all rounds handled here);
 // partialA[blk] = this workgroup's sum of w a0 a1 (32-bit words); slabs[blk] = this workgroup's histogram counters.
+// A2 / B2 (two-level eq(u_rec, g) tables, split c2) add a third histogram H2[p][e] = sum_{g : byte_p(g) = e} eq(u_rec, g): the
+// multilinear evaluations of the nb bit planes (FrTensor::partial_me(u_rec, nb), zkrelu.cu:88,93) are its bit marginals, so
+// the same pass over the words serves the partial_me that follows each bit sumcheck.
 template <int NB, class WordT>
 __device__ __forceinline__ void k_binb_words(uint32_t zk_nblk, const WordT* __restrict__ packed, uint32_t n, const Fr* __restrict__ tab_g, const Fr* __restrict__ AH,
                                                      const Fr* __restrict__ BH, uint32_t ch, const Fr* __restrict__ v, Fr* __restrict__ out, Fr* __restrict__ partialA,
-                                                     unsigned long long* __restrict__ slabs) {
-  constexpr uint32_t NPOS = NB / 8, NH = NPOS * 256, NHP = (NPOS / 2) * 256, NBINS = NH + NHP;
+                                                     unsigned long long* __restrict__ slabs, const Fr* __restrict__ A2, const Fr* __restrict__ B2, uint32_t c2) {
+  constexpr uint32_t NPOS = NB / 8, NH = NPOS * 256, NHP = (NPOS / 2) * 256, NBINS = NH + NHP + NH;
   extern __shared__ unsigned long long lds64[];
   unsigned long long* H = lds64;                                   // NBINS * 5 counters
   Fr* tab = reinterpret_cast<Fr*>(lds64 + NBINS * BINB_LIMBS_LDS);   // 768 table entries (16-byte aligned: NBINS * 40 B)
@@ -423,7 +426,7 @@ __device__ __forceinline__ void k_binb_words(uint32_t zk_nblk, const WordT* __re
   const Fr* V3 = tab;
   const Fr* VA = tab + 256;
   const Fr* VB = tab + 512;
-  const uint32_t mh = (1u << ch) - 1u;
+  const uint32_t mh = (1u << ch) - 1u, m2 = (1u << c2) - 1u;
   Fr accA = fr_zero();
   Fr v4 = fr_zero();
   if (NB == 32) v4 = v[4];
@@ -445,6 +448,20 @@ __device__ __forceinline__ void k_binb_words(uint32_t zk_nblk, const WordT* __re
         const uint32_t b = (word >> (8 * p)) & 255u;
         if (b) {
           unsigned long long* bin = H + (p * 256 + b) * BINB_LIMBS_LDS;
+#pragma unroll
+          for (int j = 0; j < 5; j++) atomicAdd(bin + j, l[j]);
+        }
+      }
+    }
+    {
+      const Fr w2 = fr_mul(A2[g & m2], B2[g >> c2]);
+      unsigned long long l[5];
+      binb_limbs51(w2, l);
+#pragma unroll
+      for (uint32_t p = 0; p < NPOS; p++) {
+        const uint32_t b = (word >> (8 * p)) & 255u;
+        if (b) {
+          unsigned long long* bin = H + (NH + NHP + p * 256 + b) * BINB_LIMBS_LDS;
 #pragma unroll
           for (int j = 0; j < 5; j++) atomicAdd(bin + j, l[j]);
         }
@@ -537,7 +554,7 @@ __device__ __forceinline__ Fr binb_bin_to_fr(const unsigned long long* __restric
 //   and c1 = p1 - c0 - c2 everywhere
 __device__ __forceinline__ void k_binb_finish(uint32_t zk_nblk, const unsigned long long* __restrict__ sums, const Fr* __restrict__ fac, const Fr* __restrict__ tab,
                                                       const Fr* __restrict__ partialA, uint32_t nA, BytesLayout L, const Fr* __restrict__ u, const Fr* __restrict__ v,
-                                                      Fr* __restrict__ proof) {
+                                                      Fr* __restrict__ proof, Fr* __restrict__ pme_out) {
   __shared__ Fr red[48];
   __shared__ Fr S[16];
   const uint32_t tid = threadIdx.x;
@@ -596,14 +613,35 @@ __device__ __forceinline__ void k_binb_finish(uint32_t zk_nblk, const unsigned l
       put(4, fr_add(S[10], m0), fr_add(S[11], m1), fr_sub(fr_add(S[12], fr_add(m0, m1)), fr_dbl(A)));
     }
   }
+  // partial_me(u_rec, nb): out[8p + j] = sum over the bytes e with bit j set of H2[p][e]; lanes [256p, 256p + 256) own position p
+  Fr h2 = fr_zero();
+  if (own) h2 = binb_bin_to_fr(sums + (size_t)(L.nH + L.nHP + tid) * BINB_LIMBS_LDS * 2);
+  const uint32_t wave = tid >> 6, lane = tid & 63u;
+  for (uint32_t j = 0; j < 8; j++) {
+    Fr x = ((tid >> j) & 1u) ? h2 : fr_zero();   // the byte value of bin tid is tid & 255
+    x = wave_sum_fr(x);
+    __syncthreads();
+    if (lane == 0) red[wave] = x;
+    __syncthreads();
+    if (lane == 0 && (wave & 3u) == 0 && tid < L.nH) pme_out[8 * (tid >> 8) + j] = fr_add(fr_add(red[wave], red[wave + 1]), fr_add(red[wave + 2], red[wave + 3]));
+  }
 }
 
 int sumcheck_bin_dev(zk_ctx* ctx, const Fr* a, uint32_t n, const Fr* u_d, const Fr* v_d, uint32_t k, Fr* proof_d);
-static int binb_sumcheck_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb, const Fr* u_d, const Fr* v_d, uint32_t k, Fr* proof_d) {
+// binary_sumcheck of the bit tensor AND its partial_me(u_rec, nb) (pme_d receives nb elements; u_rec_d holds k - log2(nb) challenges)
+int binb_sumcheck_pme_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb, const Fr* u_d, const Fr* v_d, uint32_t k, Fr* proof_d, const Fr* u_rec_d, Fr* pme_d) {
+  if (nb != 32 && nb != 16) return ctx->fail(ZK_ERR_ARG, "packed sumcheck: nb must be 16 or 32");
   const BytesLayout L = bytes_layout(nb);
+  if (n == 0 || k != ceil_log2(n) + L.lognb) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   const uint32_t kh = k - L.lognb;
   const uint32_t ch = kh < 10 ? kh : 10;
-  const uint32_t nbins = L.nH + L.nHP, ncount = nbins * BINB_LIMBS_LDS;
+  const uint32_t nbins = L.nH + L.nHP + L.nH, ncount = nbins * BINB_LIMBS_LDS;
+  ZK_ALLOC(ctx, A2, Fr, (size_t)1 << ch);
+  ZK_ALLOC(ctx, B2, Fr, (size_t)1 << (kh - ch));
+  {
+    const uint32_t nt = (1u << ch) + (1u << (kh - ch));
+    ZK_LAUNCHB(ctx, "binp_prep", 32ull * nt, 256, k_eq_pair_tables, dim3(stream_grid(nt, 256, 16)), 0, u_rec_d, kh, ch, A2.get(), B2.get());
+  }
   ZK_ALLOC(ctx, tab, Fr, 768);
   ZK_ALLOC(ctx, AH, Fr, (size_t)1 << ch);
   ZK_ALLOC(ctx, BH, Fr, (size_t)1 << (kh - ch));
@@ -627,18 +665,18 @@ static int binb_sumcheck_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32
       (void)hipGetLastError();
     }
     ZK_LAUNCHB(ctx, "binp_words", bytes, 1024, (k_binb_words<32, uint32_t>), dim3(grid), lds, (const uint32_t*)packed, n, (const Fr*)tab.get(), (const Fr*)AH.get(), (const Fr*)BH.get(), ch,
-              v_d, out.get(), partialA.get(), slabs.get());
+              v_d, out.get(), partialA.get(), slabs.get(), (const Fr*)A2.get(), (const Fr*)B2.get(), ch);
   } else {
     if (ctx->lds_first_use(zk::Kern<1024, &k_binb_words<16, uint16_t>>::desc())) {
       zk::Kern<1024, &k_binb_words<16, uint16_t>>::set_max_lds(lds);
       (void)hipGetLastError();
     }
     ZK_LAUNCHB(ctx, "binp_words", bytes, 1024, (k_binb_words<16, uint16_t>), dim3(grid), lds, (const uint16_t*)packed, n, (const Fr*)tab.get(), (const Fr*)AH.get(), (const Fr*)BH.get(), ch,
-              v_d, out.get(), partialA.get(), slabs.get());
+              v_d, out.get(), partialA.get(), slabs.get(), (const Fr*)A2.get(), (const Fr*)B2.get(), ch);
   }
   ZK_LAUNCHB(ctx, "binp_finish", 8ull * grid * ncount, 256, k_binb_reduce, dim3(stream_grid(ncount, 256, 32)), 0, (const unsigned long long*)slabs.get(), grid, ncount, sums.get());
   ZK_LAUNCHB(ctx, "binp_finish", 16ull * ncount + 32ull * L.nH * L.NF, 1024, k_binb_finish, dim3(1), 0, (const unsigned long long*)sums.get(), (const Fr*)fac.get(),
-            (const Fr*)tab.get(), (const Fr*)partialA.get(), nb == 32 ? grid : 0u, L, u_d, v_d, proof_d);
+            (const Fr*)tab.get(), (const Fr*)partialA.get(), nb == 32 ? grid : 0u, L, u_d, v_d, proof_d, pme_d);
   // rounds R .. k-1 and the final a(0): generic path on the table of one element per word
   return sumcheck_bin_dev(ctx, out.get(), n, u_d + L.R, v_d + L.R, k - L.R, proof_d + 3 * L.R);
 }
@@ -649,7 +687,6 @@ int binp_sumcheck_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb, 
   if (nb != 32 && nb != 16) return ctx->fail(ZK_ERR_ARG, "packed sumcheck: nb must be 16 or 32");
   PackedLayout L = packed_layout(nb);
   if (n == 0 || k != ceil_log2(n) + L.lognb) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
-  if (ctx->relu_bytes) return binb_sumcheck_dev(ctx, packed, n, nb, u_d, v_d, k, proof_d);
   const uint32_t kh = k - L.lognb;
   const uint32_t ch = kh < 10 ? kh : 10;
   ZK_ALLOC(ctx, tab, Fr, L.total);
