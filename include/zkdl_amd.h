@@ -249,6 +249,37 @@ int zk_transcript_seal(zk_transcript* tr, uint64_t* out8_d);
  * synchronously or was never sealed) */
 void* zk_transcript_stream(zk_transcript* tr);
 
+/* ---------------------------------------------------------------- verifier, hash-derived challenges
+ * The reference computes every proof value and drops it (zkfc.cu:139-144, zkrelu.cu:91-99); nothing in it verifies.
+ * These entry points check a proof slice WITHOUT the witness.  Proof values are passed as the serialised transcript
+ * holds them: Fr in Montgomery limbs, G1 in affine-canonical form + infinity flags (zk_transcript_serialize /
+ * zk_transcript_read_affine).  The call returns ZK_OK when it could run; *ok = 1 if every check passed, 0 otherwise
+ * (zk_last_error then names the first failed check).
+ *
+ * zk_verify_fc -- one zkFC::prove (zkfc.cu:128-145): fr_h = [ip sumcheck 3 k_in + 2][Z~(u_out||u_bs)][t(0)],
+ * g1_h = [com(u_hi)][me_open 3 k_lo + 1].  Checks the inner-product sumcheck recurrence and final product
+ * (proof.cu:55-96), t(0) = W~(u_out||u_in), and the opening against the PUBLIC commitment (commitment.cu:43-92):
+ * com(u_hi) and the final generator are recomputed from com_d / gens, T_0 = [R] com(u_hi), every round's folding
+ * relation, and T_last' = t(0) * g_final.  z_is_raw: the layer was proved on the un-Montgomery'd output (the last layer,
+ * demo.cu:119,128).  expect_z_h / expect_x_h (optional): evaluations of the layer's public output / input the transcript's
+ * claims must equal; claim_z_h / claim_x_h (optional) receive the two claims Z~(u_out||u_bs), X~(u_in||u_bs). */
+int zk_verify_fc(zk_ctx* ctx, zk_gens* gens, const zk_g1j* com_d, uint32_t m, uint32_t batch, uint32_t in, uint32_t out, int z_is_raw,
+                 const zk_fr* u_bs_h, const zk_fr* u_in_h, const zk_fr* u_out_h, const zk_fr* fr_h, size_t n_fr, const zk_g1a* g1_h, const uint8_t* inf_h,
+                 size_t n_g1, const zk_fr* expect_z_h, const zk_fr* expect_x_h, zk_fr* claim_z_h, zk_fr* claim_x_h, int* ok);
+/* zk_verify_relu -- one zkReLU::prove (zkrelu.cu:79-100) over n elements: fr_h as zk_relu_prove appends it.  Checks both
+ * binary sumchecks (proof.cu:152-188) and the Hadamard sumcheck (proof.cu:110-137).  The reference binds none of the
+ * ReLU's final evaluations to a commitment (activation commitments are its stated future work), so they are returned as
+ * open claims: claims_h[0..5) = mag_bin~(v_z), rem_bin~(v_r), (Z o sign)~(u_hp), Z~(v_hp), sign~(v_hp). */
+int zk_verify_relu(zk_ctx* ctx, uint32_t n, const zk_fr* u_z_h, const zk_fr* v_z_h, const zk_fr* u_r_h, const zk_fr* v_r_h, const zk_fr* u_hp_h,
+                   const zk_fr* v_hp_h, const zk_fr* fr_h, size_t n_fr, zk_fr* claims_h, int* ok);
+/* Challenges as hash outputs in random_vec's distribution (proof.cu:3-11): out_h[i] = SHA-256("zkdl-amd/fs/v1" | seed32 |
+ * layer | kind | vec | i) read as 8 little-endian limbs, top limb mod 1944954707.  One derivation per prove call and
+ * challenge vector (kind 0 = zkFC, 1 = zkReLU; vec = position in the reference's draw order, zkfc.cu:135-137 /
+ * zkrelu.cu:85-98), seeded by a digest of the public statement: reproducible by the verifier, independent of the call's
+ * own round messages exactly like the reference's pre-drawn coins. */
+int zk_fs_derive(const uint8_t* seed32, uint32_t layer, uint32_t kind, uint32_t vec, uint32_t len, zk_fr* out_h);
+int zk_sha256(const void* data, size_t len, uint8_t* out32);
+
 #ifdef __cplusplus
 }
 #endif

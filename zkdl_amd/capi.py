@@ -33,7 +33,8 @@ zk_set_msm_window zk_set_flag zk_gens_create zk_gens_destroy zk_gens_size zk_gen
 zk_fc_out zk_fc_com_size zk_fc_weights zk_fc_com zk_fc_load_input zk_fc_forward zk_fc_prove zk_relu_create
 zk_relu_destroy zk_relu_forward zk_relu_sign zk_relu_mag_bin zk_relu_rem_bin zk_relu_prove zk_transcript_create
 zk_transcript_destroy zk_transcript_reset zk_transcript_flush zk_transcript_counts zk_transcript_read zk_transcript_read_affine
-zk_transcript_digest zk_transcript_digest_dev zk_transcript_serialize zk_transcript_seal zk_transcript_stream""".split()
+zk_transcript_digest zk_transcript_digest_dev zk_transcript_serialize zk_transcript_seal zk_transcript_stream
+zk_verify_fc zk_verify_relu zk_fs_derive zk_sha256""".split()
 
 
 class ZkError(RuntimeError):
@@ -436,6 +437,31 @@ class Zk:
         self._chk(self.lib.zk_msm_batch(self.ctx, gens.h, _vp(scalars.ptr), _u32(q), _vp(out.ptr)))
         return out
 
+    # ---- verifier (no witness: public commitment / generators, challenges, proof values)
+    def verify_fc(self, gens, com, batch, n_in, n_out, ch, fr, aff, inf, z_is_raw=False, expect_z=None, expect_x=None):
+        """zk_verify_fc: returns (ok, message, claim_z, claim_x)."""
+        fr = np.ascontiguousarray(fr, dtype=np.uint32).reshape(-1, 8)
+        aff = np.ascontiguousarray(aff, dtype=np.uint32).reshape(-1, 24)
+        inf = np.ascontiguousarray(inf, dtype=np.uint8).reshape(-1)
+        ok = ctypes.c_int(0)
+        cz, cx = np.zeros(8, np.uint32), np.zeros(8, np.uint32)
+        ez = _hp(_fr_host(expect_z, 1)) if expect_z is not None else None
+        ex = _hp(_fr_host(expect_x, 1)) if expect_x is not None else None
+        self._chk(self.lib.zk_verify_fc(self.ctx, gens.h, _vp(com.ptr), _u32(com.n), _u32(batch), _u32(n_in), _u32(n_out), int(bool(z_is_raw)),
+                                        _hp(_fr_host(ch[0])), _hp(_fr_host(ch[1])), _hp(_fr_host(ch[2])), _hp(fr), _sz(fr.shape[0]), _hp(aff), _hp(inf), _sz(aff.shape[0]),
+                                        ez, ex, _hp(cz), _hp(cx), ctypes.byref(ok)))
+        return bool(ok.value), ("" if ok.value else self.lib.zk_last_error(self.ctx).decode()), cz, cx
+
+    def verify_relu(self, n, ch, fr):
+        """zk_verify_relu: ch in zk_relu_prove's order (7 vectors; u_rec is not used by any check).  Returns
+        (ok, message, claims[5]) -- the claims are the evaluations the reference leaves unbound."""
+        fr = np.ascontiguousarray(fr, dtype=np.uint32).reshape(-1, 8)
+        ok = ctypes.c_int(0)
+        claims = np.zeros((5, 8), np.uint32)
+        self._chk(self.lib.zk_verify_relu(self.ctx, _u32(n), _hp(_fr_host(ch[0])), _hp(_fr_host(ch[1])), _hp(_fr_host(ch[2])), _hp(_fr_host(ch[3])), _hp(_fr_host(ch[5])),
+                                          _hp(_fr_host(ch[6])), _hp(fr), _sz(fr.shape[0]), _hp(claims), ctypes.byref(ok)))
+        return bool(ok.value), ("" if ok.value else self.lib.zk_last_error(self.ctx).decode()), claims
+
     # ---- layers
     def float_to_fr(self, fs_d, rows, rows_p, cols, cols_p):
         out = self.empty(rows_p * cols_p, 8)
@@ -451,6 +477,30 @@ class Zk:
         out = self.empty(b_p * in_p, 8)
         self._chk(self.lib.zk_fc_load_input(self.ctx, _u32(batch), _u32(in_dim), _vp(x_f32_dev.ptr), _vp(out.ptr)))
         return out
+
+
+def sha256(data):
+    """SHA-256 through the library (host code; the same function zk_fs_derive hashes with)."""
+    lib = load_library()
+    out = (ctypes.c_ubyte * 32)()
+    buf = bytes(data)
+    rc = lib.zk_sha256(buf, _sz(len(buf)), out)
+    if rc != ZK_OK:
+        raise ZkError(rc, "zk_sha256 failed")
+    return bytes(out)
+
+
+def fs_derive(seed32, layer, kind, vec, n, lib=None):
+    """n challenges of one prove call's challenge vector, derived from the statement digest (zk_fs_derive)."""
+    lib = lib or load_library()
+    seed32 = bytes(seed32)
+    if len(seed32) != 32:
+        raise ValueError("seed must be 32 bytes")
+    out = np.zeros((max(n, 1), 8), dtype=np.uint32)
+    rc = lib.zk_fs_derive(seed32, _u32(layer), _u32(kind), _u32(vec), _u32(n), _hp(out))
+    if rc != ZK_OK:
+        raise ZkError(rc, "zk_fs_derive failed")
+    return out[:n]
 
 
 class Gens:

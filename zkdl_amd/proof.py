@@ -1,0 +1,142 @@
+"""Proof objects above the C ABI: the statement digest, hash-derived challenges for every prove call of the reference's
+timed loop (demo.cu:124-138), the serialised transcript split back into its calls, and the verifier loop.
+
+The verifier (`verify_mlp`) reads only public data -- generators, the layers' commitments, the network's input and
+output tensors, the challenges, the serialised proof -- and calls zk_verify_fc / zk_verify_relu (csrc/verify.hip) per
+call.  What the reference's protocol binds, it checks; what it leaves unbound (the ReLU layers' final evaluations and
+the activation-side claims between layers: "commitment of activations" is the reference's stated future work) comes
+back in `open_claims`.
+"""
+import struct
+
+import numpy as np
+
+from .capi import fs_derive, sha256
+
+KIND_FC, KIND_RELU = 0, 1
+
+
+def ceil_log2(x):
+    return 0 if x <= 1 else (x - 1).bit_length()
+
+
+def layer_shapes(dims):
+    out = []
+    for n_in, n_out in zip(dims[:-1], dims[1:]):
+        in_p, out_p = 1 << ceil_log2(n_in), 1 << ceil_log2(n_out)
+        n_g = 1 << ((ceil_log2(n_in * n_out) + 1) // 2)             # demo.cu:81 (unpadded in*out)
+        out.append(dict(n_in=n_in, n_out=n_out, in_p=in_p, out_p=out_p, n_gens=n_g, m=in_p * out_p // n_g))
+    return out
+
+
+def call_order(n_layers):
+    """(kind, layer) in the order demo.cu:128-137 proves them."""
+    out = [("fc", n_layers - 1)]
+    for i in range(n_layers - 2, -1, -1):
+        out += [("relu", i), ("fc", i)]
+    return out
+
+
+def statement_digest(zk, dims, batch, gens, coms, x_fr, y_fr):
+    """SHA-256 over everything public: shape, generators and commitments (affine-canonical bytes + infinity flags),
+    the quantised input X and the claimed output Y_hat (Fr limbs as stored)."""
+    parts = [b"zkdl-amd/statement/v1", struct.pack("<I", len(dims)), struct.pack("<%dI" % len(dims), *dims), struct.pack("<I", batch)]
+    for g, c in zip(gens, coms):
+        for pts in (g.points(), c):
+            aff, inf = zk.g1_to_affine(pts)
+            parts += [sha256(aff.tobytes()), sha256(inf.tobytes())]
+    parts += [sha256(x_fr.download().tobytes()), sha256(y_fr.download().tobytes())]
+    return sha256(b"".join(parts))
+
+
+def fs_challenges(seed, dims, batch):
+    """Challenge vectors of every prove call, in call order, each derived from (seed, layer, kind, position in the
+    reference's draw order: zkfc.cu:135-137 u_bs,u_in,u_out / zkrelu.cu:85-98 u_z,v_z,u_r,v_r,u_rec,u_hp,v_hp)."""
+    sh = layer_shapes(dims)
+    kb = ceil_log2(1 << ceil_log2(batch))
+    out = []
+    for kind, i in call_order(len(sh)):
+        s = sh[i]
+        if kind == "fc":
+            lens = (kb, ceil_log2(s["in_p"]), ceil_log2(s["out_p"]))
+            out.append(("fc", i, [fs_derive(seed, i, KIND_FC, v, n) for v, n in enumerate(lens)]))
+        else:
+            k = kb + ceil_log2(s["out_p"])
+            lens = (k + 5, k + 5, k + 4, k + 4, k, k, k)
+            out.append(("relu", i, [fs_derive(seed, i, KIND_RELU, v, n) for v, n in enumerate(lens)]))
+    return out
+
+
+def parse_transcript(blob):
+    """zk_transcript_serialize's format -> (Fr (n, 8), affine G1 (n, 24), infinity flags (n,))."""
+    if blob[:8] != b"ZKDLTR01":
+        raise ValueError("not a zkdl_amd transcript")
+    n_fr, n_g1 = struct.unpack("<QQ", blob[8:24])
+    need = 24 + 32 * n_fr + 97 * n_g1
+    if len(blob) != need:
+        raise ValueError("transcript length %d does not match its header (%d)" % (len(blob), need))
+    off = 24
+    fr = np.frombuffer(blob, dtype=np.uint32, count=8 * n_fr, offset=off).reshape(-1, 8)
+    off += 32 * n_fr
+    aff = np.frombuffer(blob, dtype=np.uint32, count=24 * n_g1, offset=off).reshape(-1, 24)
+    off += 96 * n_g1
+    inf = np.frombuffer(blob, dtype=np.uint8, count=n_g1, offset=off)
+    return fr, aff, inf
+
+
+def split_calls(dims, batch, fr, aff, inf):
+    """Per-call slices of a whole-MLP transcript (SURVEY.md App. A.6 order)."""
+    sh = layer_shapes(dims)
+    kb = ceil_log2(1 << ceil_log2(batch))
+    out, of, og = [], 0, 0
+    for kind, i in call_order(len(sh)):
+        s = sh[i]
+        if kind == "fc":
+            nf, ng = 3 * ceil_log2(s["in_p"]) + 4, 3 * ceil_log2(s["n_gens"]) + 2
+        else:
+            k = kb + ceil_log2(s["out_p"])
+            nf, ng = 3 * (k + 5) + 1 + 32 + 3 * (k + 4) + 1 + 16 + 3 * k + 2, 0
+        out.append((kind, i, fr[of:of + nf], aff[og:og + ng], inf[og:og + ng]))
+        of += nf
+        og += ng
+    if of != fr.shape[0] or og != aff.shape[0]:
+        raise ValueError("transcript does not have the shape of this model's proof")
+    return out
+
+
+def verify_mlp(zk, dims, batch, gens, coms, x_fr, y_fr, blob, chal=None):
+    """Verify a serialised whole-MLP proof.  gens[i]: the layer's Gens handle; coms[i]: DevArray of its commitment
+    points; x_fr / y_fr: the public quantised input (Montgomery form, padded) and output Y_hat (un-Montgomery'd, as
+    demo.out holds it).  chal: the challenges (default: derived from the statement digest).  Returns
+    (ok, message, open_claims) -- open_claims lists the evaluations the reference's protocol leaves unbound."""
+    sh = layer_shapes(dims)
+    L = len(sh)
+    B_p = 1 << ceil_log2(batch)
+    if chal is None:
+        chal = fs_challenges(statement_digest(zk, dims, batch, gens, coms, x_fr, y_fr), dims, batch)
+    try:
+        fr, aff, inf = parse_transcript(blob)
+        calls = split_calls(dims, batch, fr, aff, inf)
+    except ValueError as e:
+        return False, str(e), []
+    open_claims = []
+    for (kind, i, f, a, nf), (ckind, ci, ch) in zip(calls, chal):
+        assert (kind, i) == (ckind, ci)
+        s = sh[i]
+        if kind == "fc":
+            # the first call opens the public output, the last one the public input
+            expect_z = zk.fr_me(y_fr, np.concatenate([ch[2], ch[0]])) if i == L - 1 else None
+            expect_x = zk.fr_me(x_fr, np.concatenate([ch[1], ch[0]])) if i == 0 else None
+            ok, msg, cz, cx = zk.verify_fc(gens[i], coms[i], B_p, s["in_p"], s["out_p"], ch, f, a, nf, z_is_raw=(i == L - 1), expect_z=expect_z, expect_x=expect_x)
+            if not ok:
+                return False, "zkFC layer %d: %s" % (i, msg), open_claims
+            if i != L - 1:
+                open_claims.append(("Z_%d~(u_out||u_bs)" % i, cz))
+            if i != 0:
+                open_claims.append(("A_%d~(u_in||u_bs)" % (i - 1), cx))
+        else:
+            ok, msg, claims = zk.verify_relu(B_p * s["out_p"], ch, f)
+            if not ok:
+                return False, "zkReLU layer %d: %s" % (i, msg), open_claims
+            open_claims += [("relu_%d:%s" % (i, nm), c) for nm, c in zip(("mag_bin~(v_z)", "rem_bin~(v_r)", "(Z.sign)~(u_hp)", "Z~(v_hp)", "sign~(v_hp)"), claims)]
+    return True, "", open_claims
