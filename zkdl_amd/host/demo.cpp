@@ -1,5 +1,5 @@
 // zkdl_amd/host/demo.cpp -- the reference driver (demo.cu) on the MI355X library.
-//   ./demo traced_model.pt sample_input.pt [--seed S] [--dump DIR]
+//   ./demo traced_model.pt sample_input.pt [--seed S] [--dump DIR] [--fs] [--verify]
 // Same CLI, same inputs (TorchScript nn.Sequential of bias-free Linear + ReLU; a tensor saved as
 // parameter "0" of a scripted empty module, model.py:4-8), same outputs: demo.out (Y_hat, one
 // 0x%064x per line, demo.cu:119-122) and the three stdout lines (demo.cu:92,140-141).
@@ -7,10 +7,15 @@
 // weight tensor is kept alive while its pointer is used (the reference dangles, demo.cu:78).
 // --dump DIR additionally writes what a checker needs to replay the proof: gens_<i>.bin (the randomised generators,
 // Jacobian), challenges.bin (every random_vec draw, in order) and transcript.bin (zk_transcript_serialize).
+// --fs derives the challenges of every prove call from SHA-256(model file | input file | commitments) (zk_fs_derive) instead of
+// the seeded generator; --verify then checks the serialised proof call by call with zk_verify_fc / zk_verify_relu, reading
+// only public data (generators, commitments, the input and output tensors), and prints "Verification: OK" or the failed check.
 #include <torch/script.h>
 #include <torch/torch.h>
 
+#include <cstring>
 #include <fstream>
+#include <iterator>
 #include <iostream>
 #include <memory>
 #include <string>
@@ -83,11 +88,14 @@ int main(int argc, char* argv[]) {
   }
   string dump_dir;
   vector<Fr_t> challenges;
-  for (int i = 3; i + 1 < argc; i++) {
-    if (string(argv[i]) == "--seed") zkdl::seed(strtoull(argv[i + 1], nullptr, 0));
-    if (string(argv[i]) == "--dump") dump_dir = argv[i + 1];
+  bool use_fs = false, do_verify = false;
+  for (int i = 3; i < argc; i++) {
+    if (string(argv[i]) == "--seed" && i + 1 < argc) zkdl::seed(strtoull(argv[i + 1], nullptr, 0));
+    if (string(argv[i]) == "--dump" && i + 1 < argc) dump_dir = argv[i + 1];
+    if (string(argv[i]) == "--fs") use_fs = true;
+    if (string(argv[i]) == "--verify") do_verify = true;
   }
-  if (!dump_dir.empty()) zkdl::challenge_log() = &challenges;
+  zkdl::challenge_log() = &challenges;
   vector<unique_ptr<Commitment>> generators;
   vector<zkFC> fcs = load_model(argv[1], generators);
   vector<zkReLU> relus(fcs.size() - 1);
@@ -105,14 +113,35 @@ int main(int argc, char* argv[]) {
   outfile << Y_hat << endl;
   outfile.close();
 
+  auto num_layer = fcs.size();
+  if (use_fs) {  // statement digest: the two input files and every layer's commitment points
+    auto slurp = [](const char* path) { ifstream f(path, ios::binary); return string((istreambuf_iterator<char>(f)), istreambuf_iterator<char>()); };
+    string st = "zkdl-amd/demo/v1";
+    uint8_t d[32];
+    for (const char* path : {argv[1], argv[2]}) {
+      string bytes = slurp(path);
+      zk_sha256(bytes.data(), bytes.size(), d);
+      st.append(reinterpret_cast<char*>(d), 32);
+    }
+    for (auto& fc : fcs) {
+      vector<G1Jacobian_t> c(fc.commitment_size());
+      zkdl::check(zk_memcpy_d2h(zkdl::ctx(), c.data(), fc.commitment_points(), c.size() * sizeof(G1Jacobian_t)));
+      zk_sha256(c.data(), c.size() * sizeof(G1Jacobian_t), d);
+      st.append(reinterpret_cast<char*>(d), 32);
+    }
+    zk_sha256(st.data(), st.size(), d);
+    zkdl::fs_begin(d);
+  }
   Timer timer;
   zk_ctx_sync(zkdl::ctx());
   timer.start();
-  auto num_layer = fcs.size();
+  if (use_fs) zkdl::fs_call(num_layer - 1, 0);
   fcs[num_layer - 1].prove(A_vec[num_layer - 2], Y_hat, *generators[num_layer - 1]);
   for (int i = num_layer - 2; i >= 0; --i) {
+    if (use_fs) zkdl::fs_call(i, 1);
     relus[i].prove(Z_vec[i], A_vec[i]);
     FrTensor& A_ = (i > 0) ? A_vec[i - 1] : X;
+    if (use_fs) zkdl::fs_call(i, 0);
     fcs[i].prove(A_, Z_vec[i], *generators[i]);
   }
   zk_transcript_flush(zkdl::transcript());   // the deferred MSM batch belongs to the timed region
@@ -126,6 +155,49 @@ int main(int argc, char* argv[]) {
   cout << "Proof time: " << timer.getTotalTime() / batch_size << " seconds per data point." << endl;
   cout << "Current HIP status: " << 0 << endl;
   cout << "Transcript: " << n_fr << " Fr + " << n_g1 << " G1 values, digest " << digest << endl;
+  if (do_verify) {  // the verifier's pass: public data + the serialised proof only
+    size_t len = 0;
+    zk_transcript_serialize(zkdl::transcript(), nullptr, 0, &len);
+    vector<unsigned char> buf(len);
+    zkdl::check(zk_transcript_serialize(zkdl::transcript(), buf.data(), buf.size(), &len));
+    vector<Fr_t> fr(n_fr);
+    vector<G1Affine_t> g1(n_g1);
+    vector<uint8_t> inf(n_g1);
+    memcpy(fr.data(), buf.data() + 24, n_fr * sizeof(Fr_t));
+    memcpy(g1.data(), buf.data() + 24 + n_fr * sizeof(Fr_t), n_g1 * sizeof(G1Affine_t));
+    memcpy(inf.data(), buf.data() + 24 + n_fr * sizeof(Fr_t) + n_g1 * sizeof(G1Affine_t), n_g1);
+    const uint B_p = 1u << ceilLog2(batch_size);
+    size_t of = 0, og = 0, oc = 0;
+    auto take = [&](uint n) { vector<Fr_t> v(challenges.begin() + oc, challenges.begin() + oc + n); oc += n; return v; };
+    string verdict;
+    auto verify_fc = [&](int i) {
+      const zkFC& fc = fcs[i];
+      auto u_bs = take(ceilLog2(B_p)), u_in = take(ceilLog2(fc.inputSize)), u_out = take(ceilLog2(fc.outputSize));
+      const size_t nf = 3 * ceilLog2(fc.inputSize) + 4, ng = 3 * ceilLog2(generators[i]->size) + 2;
+      Fr_t ez, ex;
+      const bool last = i == (int)num_layer - 1, first = i == 0;
+      if (last) { auto uz = concatenate<Fr_t>({u_out, u_bs}); ez = Y_hat(uz); }
+      if (first) { auto ux = concatenate<Fr_t>({u_in, u_bs}); ex = X(ux); }
+      string msg = fc.verify(B_p, *generators[i], last, u_bs, u_in, u_out, fr.data() + of, nf, g1.data() + og, inf.data() + og, ng, last ? &ez : nullptr, first ? &ex : nullptr);
+      of += nf;
+      og += ng;
+      if (!msg.empty() && verdict.empty()) verdict = "zkFC layer " + to_string(i) + ": " + msg;
+    };
+    verify_fc(num_layer - 1);
+    for (int i = num_layer - 2; i >= 0; --i) {
+      const uint n = B_p * fcs[i].outputSize, k = ceilLog2(n);
+      vector<vector<Fr_t>> ch;
+      for (uint l : {k + 5, k + 5, k + 4, k + 4, k, k, k}) ch.push_back(take(l));
+      const size_t nf = 3 * (k + 5) + 1 + 32 + 3 * (k + 4) + 1 + 16 + 3 * k + 2;
+      string msg = zkReLU::verify(n, ch, fr.data() + of, nf);
+      of += nf;
+      if (!msg.empty() && verdict.empty()) verdict = "zkReLU layer " + to_string(i) + ": " + msg;
+      verify_fc(i);
+    }
+    if (of != n_fr || og != n_g1 || oc != challenges.size()) verdict = "transcript does not have the shape of this model's proof";
+    cout << "Verification: " << (verdict.empty() ? "OK" : verdict) << endl;
+    if (!verdict.empty()) return 1;
+  }
   if (!dump_dir.empty()) {
     auto put = [&](const string& name, const void* p, size_t bytes) {
       ofstream f(dump_dir + "/" + name, ios::binary);

@@ -204,10 +204,28 @@ namespace zkdl {
 // additive: when set, every challenge random_vec hands out is also appended here, in draw order (demo --dump:
 // lets a checker replay the proof with the same challenges; the reference draws them and forgets them, proof.cu:3-11)
 inline std::vector<Fr_t>*& challenge_log() { static std::vector<Fr_t>* p = nullptr; return p; }
+// additive: hash-derived challenges.  After fs_begin(statement digest), fs_call(layer, kind) before a prove call makes that
+// call's random_vec draws zk_fs_derive(seed, layer, kind, 0), (.., 1), ... in the reference's draw order; a verifier that
+// knows the statement re-derives them (include/zkdl_amd.h: zk_fs_derive).  fs_end() returns to the seeded generator.
+struct FsState {
+  bool on = false;
+  uint8_t seed[32] = {};
+  uint32_t layer = 0, kind = 0, vec = 0;
+};
+inline FsState& fs() { static FsState s; return s; }
+inline void fs_begin(const uint8_t seed32[32]) { FsState& f = fs(); f.on = true; for (int i = 0; i < 32; i++) f.seed[i] = seed32[i]; f.vec = 0; }
+inline void fs_call(uint32_t layer, uint32_t kind) { FsState& f = fs(); f.layer = layer; f.kind = kind; f.vec = 0; }
+inline void fs_end() { fs().on = false; }
 }  // namespace zkdl
 inline std::vector<Fr_t> random_vec(uint len) {
-  zkdl::ensure_seeded();
   std::vector<Fr_t> out(len);
+  if (zkdl::fs().on) {
+    zkdl::FsState& f = zkdl::fs();
+    zkdl::check(zk_fs_derive(f.seed, f.layer, f.kind, f.vec++, len, out.data()));
+    if (zkdl::challenge_log()) zkdl::challenge_log()->insert(zkdl::challenge_log()->end(), out.begin(), out.end());
+    return out;
+  }
+  zkdl::ensure_seeded();
   zkdl::check(zk_random_vec(zkdl::ctx(), len, out.data()));
   if (zkdl::challenge_log()) zkdl::challenge_log()->insert(zkdl::challenge_log()->end(), out.begin(), out.end());
   return out;
@@ -449,6 +467,8 @@ class zkFC {
   zkFC(const zkFC&) = delete;   // the reference deep-copies on vector growth (no move ctor); here vectors move
   zkFC(zkFC&& o) noexcept : h_(o.h_), inputSize(o.inputSize), outputSize(o.outputSize) { o.h_ = nullptr; }
   ~zkFC() { if (h_) zk_fc_destroy(h_); }
+  uint commitment_size() const { return zk_fc_com_size(h_); }                 // additive: the public commitment `com` (zkfc.cuh:22)
+  const G1Jacobian_t* commitment_points() const { return zk_fc_com(h_); }     // device pointer
   FrTensor operator()(const FrTensor& X) const {   // zkfc.cu:117-126
     if (X.size % inputSize != 0) throw std::runtime_error("Incompatible dimensions");
     FrTensor out(X.size / inputSize * outputSize);
@@ -463,6 +483,16 @@ class zkFC {
     auto u_out_dim = random_vec(ceilLog2(outputSize));
     zkdl::check(zk_fc_prove(zkdl::ctx(), h_, X.gpu_data, X.size, Z.gpu_data, Z.size, generators.handle(), u_bs.data(), u_in_dim.data(), u_out_dim.data(),
                             zkdl::transcript()));
+  }
+  // additive (the reference has no verifier): check this layer's slice of a serialised proof against the layer's public
+  // commitment; challenges in zkfc.cu:135-137's order.  Returns the first failed check's message, empty when it verifies.
+  std::string verify(uint batch_size, const Commitment& generators, bool z_is_raw, const std::vector<Fr_t>& u_bs, const std::vector<Fr_t>& u_in_dim,
+                     const std::vector<Fr_t>& u_out_dim, const Fr_t* fr, size_t n_fr, const G1Affine_t* g1, const uint8_t* inf, size_t n_g1,
+                     const Fr_t* expect_z = nullptr, const Fr_t* expect_x = nullptr) const {
+    int ok = 0;
+    zkdl::check(zk_verify_fc(zkdl::ctx(), generators.handle(), zk_fc_com(h_), zk_fc_com_size(h_), batch_size, inputSize, outputSize, z_is_raw ? 1 : 0, u_bs.data(),
+                             u_in_dim.data(), u_out_dim.data(), fr, n_fr, g1, inf, n_g1, expect_z, expect_x, nullptr, nullptr, &ok));
+    return ok ? std::string() : std::string(zk_last_error(zkdl::ctx()));
   }
   static zkFC from_float_gpu_ptr(uint input_size, uint output_size, float* float_gpu_ptr, const Commitment& generators) {   // zkfc.cu:90-100
     zk_fc* h = nullptr;
@@ -502,6 +532,14 @@ class zkReLU {
     auto u_hp = random_vec(log_size), v_hp = random_vec(log_size);
     zkdl::check(zk_relu_prove(zkdl::ctx(), h_, X.gpu_data, Z.gpu_data, X.size, u_z_bin.data(), v_z_bin.data(), u_r_bin.data(), v_r_bin.data(), u_recover.data(),
                               u_hp.data(), v_hp.data(), zkdl::transcript()));
+  }
+  // additive: the verifier's checks of one zkReLU::prove slice (challenge vectors in zkrelu.cu:85-98's order; u_recover enters no
+  // check); claims5 receives the five evaluations the reference leaves unbound
+  static std::string verify(uint n, const std::vector<std::vector<Fr_t>>& ch, const Fr_t* fr, size_t n_fr, Fr_t* claims5 = nullptr) {
+    if (ch.size() != 7) throw std::runtime_error("Incompatible dimensions");
+    int ok = 0;
+    zkdl::check(zk_verify_relu(zkdl::ctx(), n, ch[0].data(), ch[1].data(), ch[2].data(), ch[3].data(), ch[5].data(), ch[6].data(), fr, n_fr, claims5, &ok));
+    return ok ? std::string() : std::string(zk_last_error(zkdl::ctx()));
   }
 };
 
