@@ -77,3 +77,35 @@ def test_bench_launches_its_own_ranks(world):
 def test_bench_launcher_propagates_a_dead_rank():
     out = _run_bench("--gpus", "2", "--launcher-selftest", "1")
     assert out.returncode == 3
+
+
+def _gather_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from zkdl_amd.shard import dist_allgather
+    payload = [dict(a=np.full((3, 8), rank, dtype=np.uint32), z=np.arange(8, dtype=np.uint32).reshape(1, 8) + rank), dict(fr=np.full((5, 8), 10 * rank, dtype=np.uint32))]
+    got = dist_allgather(payload)
+    out[rank] = all(int(got[r][0]["a"][0, 0]) == r and int(got[r][1]["fr"][4, 7]) == 10 * r and int(got[r][0]["z"][0, 1]) == 1 + r for r in range(world)) and len(got) == world
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_payload_allgather_over_gloo():
+    """The sharded prover's only exchange (zkdl_amd/shard.py: two all-gathers of per-call payloads), world size 2 on CPU."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gather_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert out[0] and out[1]
+
+
+def test_shard_rank_weights_are_the_eq_polynomial():
+    from zkdl_amd.shard import _to_int, _to_mont, eq_weight
+    rng = np.random.default_rng(2)
+    u = rng.integers(0, 1 << 32, size=(3, 8), dtype=np.uint64).astype(np.uint32)
+    u[:, 7] %= 1944954707
+    ws = [_to_int(eq_weight(u, r)) for r in range(8)]
+    assert sum(ws) % R_MOD == 1                                   # the eq weights of all ranks sum to one
+    uv = [_to_int(x) for x in u]
+    assert ws[5] == uv[0] * (1 - uv[1]) * uv[2] % R_MOD           # rank 5 = bits (1, 0, 1), LSB first
+    assert _to_int(eq_weight(u[:0], 0)) == 1 and _to_int(_to_mont(12345)) == 12345

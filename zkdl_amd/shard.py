@@ -1,0 +1,203 @@
+"""ONE proof sharded over N GPUs by batch (the reference lists multi-GPU as future work).
+
+Every activation-side table of the proof -- X, Z_i, A_i, sign, the bit tensors -- is indexed batch-major
+(flat index b * dim + j, zkfc.cu:86,119-122), so the batch bits are the HIGH variables of every multilinear table.
+Rank r holds rows [r B/N, (r+1) B/N) and all challenges are known before any kernel runs, so:
+
+  * a sumcheck over a table of k variables splits into the k - log N LOW rounds, which each rank runs on its own
+    shard with the ordinary kernels (zk_relu_prove on the shard with the challenge vectors truncated to the local
+    variables), and the log N TOP rounds over the N values the shards folded to.  Round r < k - log N of the whole
+    table has coefficients  sum_rank eq(u_top, rank) * c^(rank)  (the eq weight of a pair factors into its local
+    and its rank part); the top rounds are a sumcheck over an N-element table -- the same library call on N elements;
+  * partial_me / multilinear evaluations over the batch bits are eq(u_top, rank)-weighted sums of the shards' values;
+  * the weight side (W.partial_me, the inner-product sumcheck, the opening: all batch-independent) is split by layer:
+    layer i belongs to rank i mod N.
+
+Communication per proof: TWO all-gathers of a few KB..100 KB (the shards' local transcripts and folded vectors; then the
+owners' FC results) -- no per-round exchange.  Both phases run through the ordinary recorded / zipped prove path.  The assembled transcript is the single-GPU transcript bit for bit
+(tests/test_gpu_shard.py), so the verifier does not know the proof was sharded.
+"""
+import numpy as np
+
+from .proof import call_order, ceil_log2, layer_shapes
+
+R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+_RINV = pow(1 << 256, -1, R_MOD)
+
+
+def _to_int(limbs):                      # Montgomery limbs -> field value
+    return int.from_bytes(np.ascontiguousarray(limbs, dtype=np.uint32).tobytes(), "little") * _RINV % R_MOD
+
+
+def _to_mont(x):
+    return np.frombuffer(((x % R_MOD) * (1 << 256) % R_MOD).to_bytes(32, "little"), dtype=np.uint32).copy()
+
+
+def eq_weight(u_top, rank):
+    """eq(u_top, rank) as a Montgomery-form element: prod_t (bit_t(rank) ? u_t : 1 - u_t), LSB-first."""
+    w = 1
+    for t, ut in enumerate(np.asarray(u_top).reshape(-1, 8)):
+        v = _to_int(ut)
+        w = w * (v if (rank >> t) & 1 else (1 - v)) % R_MOD
+    return _to_mont(w)
+
+
+def relu_lens(k):
+    return (k + 5, k + 5, k + 4, k + 4, k, k, k)
+
+
+class Shard:
+    """One rank's part of one proof: its rows of the batch, the replicated layers (bench.Workload with rows=...)."""
+
+    def __init__(self, wl, rank, world):
+        self.wl, self.rank, self.world, self.zk = wl, rank, world, wl.zk
+        self.lw = ceil_log2(world)
+        if 1 << self.lw != world or wl.B_p * world != (1 << ceil_log2(wl.B_p * world)):
+            raise ValueError("world size and the local batch must be powers of two")
+
+    # ---- phase 1: everything that reads this rank's activations
+    def local_phase(self, chal):
+        """All ReLU calls of the proof on this rank's rows, recorded into ONE transcript (so they run zipped across layers
+        like an unsharded proof), plus the batch-side contractions of every zkFC call."""
+        from .capi import Transcript
+        wl, zk = self.wl, self.zk
+        sh, L = wl.shapes, len(wl.shapes)
+        kb_l = ceil_log2(wl.B_p)
+        out = []
+        tr = Transcript(zk)
+        relu_lens_seen = []
+        for kind, i, ch in chal:
+            s = sh[i]
+            if kind == "fc":
+                u_bs, u_in, u_out = ch
+                w = eq_weight(u_bs[kb_l:], self.rank)
+                x_in = wl.A[i - 1] if i > 0 else wl.X
+                z_out = wl.Yhat if i == L - 1 else wl.Z[i]
+                a_loc = zk.fr_mul_scalar(zk.fr_partial_me(x_in, u_bs[:kb_l], s["in_p"]), w)       # X~(., u_bs) restricted to this rank's rows
+                out.append(dict(a=a_loc))
+            else:
+                k_l = kb_l + ceil_log2(s["out_p"])
+                lens = relu_lens(k_l)
+                wl.relus[i].prove(wl.Z[i], wl.A[i], [c[:n] for c, n in zip(ch, lens)], tr)
+                relu_lens_seen.append(3 * (k_l + 5) + 1 + 32 + 3 * (k_l + 4) + 1 + 16 + 3 * k_l + 2)
+                out.append(dict(fr=None))
+        fr, _ = tr.read()
+        tr.close()
+        off = 0
+        it = iter(relu_lens_seen)
+        for part in out:
+            if "fr" in part:
+                n = next(it)
+                part["fr"] = fr[off:off + n].copy()
+                off += n
+            else:
+                part["a"] = part["a"].download()
+        return out
+
+    # ---- phase 2 (after the first all-gather): the weight side of the layers this rank owns
+    def owner_phase(self, chal, gathered):
+        """zkFC::prove of the owned layers through the ordinary recorded path, on BATCH-1 stand-ins: X.partial_me(u_bs)
+        is the all-reduced vector a (a 1 x in tensor: with no batch challenge partial_me is the identity), and
+        Z~(u_out || u_bs) = (a W)~(u_out), so Z's stand-in is the layer applied to a (un-Montgomery'd for the last layer,
+        demo.cu:119).  The inner-product sumcheck and the opening never see the batch."""
+        from .capi import Transcript
+        zk, wl = self.zk, self.wl
+        sh, L = wl.shapes, len(wl.shapes)
+        mine = [c for c, (kind, i, ch) in enumerate(chal) if kind == "fc" and i % self.world == self.rank]
+        if not mine:
+            return {}
+        tr = Transcript(zk)
+        keep = []
+        for c in mine:
+            _, i, (u_bs, u_in, u_out) = chal[c]
+            a = None
+            for r in range(self.world):
+                ar = zk.upload(gathered[r][c]["a"])
+                a = ar if a is None else zk.fr_add(a, ar)
+            z = wl.fcs[i].forward(a)
+            if i == L - 1:
+                z = zk.fr_unmont(z)
+            wl.fcs[i].prove(a, z, wl.gens[i], u_bs[:0], u_in, u_out, tr)
+            keep.append((a, z))
+        fr, _ = tr.read()
+        aff, inf = tr.read_affine()
+        tr.close()
+        out, of, og = {}, 0, 0
+        for c in mine:
+            s = sh[chal[c][1]]
+            nf, ng = 3 * ceil_log2(s["in_p"]) + 4, 3 * ceil_log2(s["n_gens"]) + 2
+            out[c] = dict(fr=fr[of:of + nf].copy(), aff=aff[og:og + ng].copy(), inf=inf[og:og + ng].copy())
+            of += nf
+            og += ng
+        return out
+
+    # ---- assembly (after the second all-gather): identical on every rank
+    def assemble(self, chal, gathered, owned):
+        """gathered[r][c]: rank r's phase-1 payload of call c; owned[c]: the owner's FC result of call c."""
+        zk, wl, lw, N = self.zk, self.wl, self.lw, self.world
+        sh = wl.shapes
+        kb_l = ceil_log2(wl.B_p)
+        frs, affs, infs = [], [], []
+        for c, (kind, i, ch) in enumerate(chal):
+            if kind == "fc":
+                frs.append(owned[c]["fr"])
+                affs.append(owned[c]["aff"])
+                infs.append(owned[c]["inf"])
+                continue
+            s = sh[i]
+            k_l = kb_l + ceil_log2(s["out_p"])
+            parts = [gathered[r][c]["fr"] for r in range(N)]
+            off = 0
+            pieces = []
+
+            def combine(n_vals, u_top):
+                """sum_rank eq(u_top, rank) * part[off : off + n_vals]"""
+                acc = None
+                for r in range(N):
+                    t = zk.fr_mul_scalar(zk.upload(parts[r][off:off + n_vals]), eq_weight(u_top, r))
+                    acc = t if acc is None else zk.fr_add(acc, t)
+                return acc.download()
+
+            for (u, v, kk, nb) in ((ch[0], ch[1], k_l + 5, 32), (ch[2], ch[3], k_l + 4, 16)):
+                pieces.append(combine(3 * kk, u[kk:]))                                   # the low rounds' coefficients
+                off += 3 * kk
+                finals = zk.upload(np.stack([parts[r][off] for r in range(N)]))          # each shard's table folded to one value
+                off += 1
+                pieces.append(zk.sumcheck_binary(finals, u[kk:], v[kk:]) if lw else finals.download())   # the log N top rounds + a(0)
+                pieces.append(combine(nb, ch[4][k_l:]))                                  # partial_me(u_rec, nb)
+                off += nb
+            pieces.append(combine(3 * k_l, ch[5][k_l:]))                                 # Hadamard: low rounds
+            off += 3 * k_l
+            fa = zk.upload(np.stack([parts[r][off] for r in range(N)]))
+            fb = zk.upload(np.stack([parts[r][off + 1] for r in range(N)]))
+            pieces.append(zk.sumcheck_hadamard(fa, fb, ch[5][k_l:], ch[6][k_l:]) if lw else np.concatenate([fa.download(), fb.download()]))
+            frs.append(np.concatenate(pieces))
+        return np.concatenate(frs), np.concatenate(affs), np.concatenate(infs)
+
+
+def prove_sharded(shards, chal, allgather=None):
+    """Run one sharded proof.  `shards`: this process's Shard objects -- all N of them when the ranks are simulated in one
+    process (tests), exactly one under torch.distributed, in which case `allgather(obj) -> [obj of rank 0, ..., N-1]`
+    is the collective (zkdl_amd.shard.dist_allgather).  Returns (Fr (n, 8), affine G1 (n, 24), infinity flags)."""
+    if allgather is None:
+        assert len(shards) == shards[0].world
+        gathered = [sh.local_phase(chal) for sh in shards]
+        owned = {}
+        for sh in shards:
+            owned.update(sh.owner_phase(chal, gathered))
+        return shards[0].assemble(chal, gathered, owned)
+    (sh,) = shards
+    gathered = allgather(sh.local_phase(chal))
+    owned = {}
+    for part in allgather(sh.owner_phase(chal, gathered)):
+        owned.update(part)
+    return sh.assemble(chal, gathered, owned)
+
+
+def dist_allgather(obj):
+    """all_gather of a picklable payload over the default process group (RCCL on GPUs: the byte tensors travel through
+    device memory; gloo on CPU).  Payloads are a few KB to ~100 KB per rank."""
+    import torch.distributed as dist
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
