@@ -497,14 +497,21 @@ def main():
     #   Hadamard / inner-product round: unit = a pair of both tables, 192 B, 7 / 5 products ; contraction: unit = an element, 32 B, 1 product
     fam = {"sumcheck_bin_round": (["k_many", "k_sc_roundILi2ELi1E"], 96, 6), "sumcheck_hp_round": (["k_many", "k_sc_roundILi1ELi1E"], 192, 7),
            "sumcheck_ip_round": (["k_many", "k_sc_roundILi0ELi1E"], 192, 5), "fr_contract": (["k_many", "k_colsum"], 32, 1),
-           "binp_bytes": (["k_many", "k_binp_bytes"], None, None), "binp_rounds": (["k_many", "k_binp_rounds"], None, None), "msm_accum": (["k_msm_accum"], 100, None)}
+           # byte-histogram pass: unit = one 32-bit magnitude word + one 16-bit remainder word (4 + 32 and 2 + 32 bytes), 7 + 3 products
+           # (word weights for the sumcheck and the partial_me, the cross terms, the round-4 product, the folded output)
+           "binp_words": (["k_many", "k_binb_words"], 70, 10), "msm_accum": (["k_msm_accum"], 100, None)}
     macs_per_launch = {}
     for k, v in prof.items():
         if k in fam and fam[k][2] is not None:
             macs_per_launch[k] = v["bytes"] / max(v["launches"], 1) / fam[k][1] * fam[k][2] * FR_MACS
+    # MSM items of one proof: the launch is sized for n * W slots per job (its `bytes`), but T0_r / T1_r only touch every other
+    # generator (their other scalars are zero and are dropped by the sort): per layer 2 k_lo n + n (T, T0, T1 of every round, the
+    # final generator) + m (com(u_hi)) nonzero full-width scalars, 26 ten-bit windows each
+    real_pairs = sum(2 * ceil_log2(s_["n_gens"]) * s_["n_gens"] + s_["n_gens"] + s_["m"] for s_ in wl.shapes)
     if "msm_accum" in prof:
-        items = prof["msm_accum"]["bytes"] / 100.0          # ZK_LAUNCH passes 100 B per (pair, window) item
-        macs_per_launch["msm_accum"] = items * 10 * FP_MACS / max(prof["msm_accum"]["launches"], 1)   # 8M + 2S per XYZZ mixed add
+        slots = prof["msm_accum"]["bytes"] / 100.0 / max(prof["msm_accum"]["launches"], 1)
+        items = min(slots, real_pairs * 26.0) if args.msm == "pippenger" and not args.msm_window else slots
+        macs_per_launch["msm_accum"] = items * 10 * FP_MACS   # 8M + 2S per XYZZ mixed add
     pmc_path = os.path.join(ROOT, "profiles", "pmc_r02.json")
     pmc_all = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
     cands = [k for k in kernels if k in macs_per_launch] or list(kernels)[:1]
@@ -542,7 +549,7 @@ def main():
            "g1_msm_mops_commit": wl.info["commit_mops"]}
     if "msm_accum" in prof:
         g1_ms = sum(prof[k]["ms"] for k in prof if k.startswith("msm_") or k == "g1_canonicalise") / nprof
-        out["g1_msm_mops_prove"] = (prof["msm_accum"]["bytes"] / 100.0 / 26.0 / nprof) / g1_ms / 1e3 if g1_ms > 0 else None   # full-width pairs of one proof / its G1 kernels' time
+        out["g1_msm_mops_prove"] = real_pairs / g1_ms / 1e3 if g1_ms > 0 else None   # nonzero full-width (point, scalar) pairs of one proof / its G1 kernels' time
     if rank == 0 and not args.no_msm_probe and args.workload.startswith("mlp18m"):
         out["g1_msm_fullwidth"] = msm_fullwidth_probe(zk)
         out["g1_msm_mops"] = out["g1_msm_fullwidth"]["mops"]

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4]: the 2^24-point MSM stress with the Pippenger window-width sweep, on one GPU, through the C ABI.
+4096 generators x 4096 rows = 2^24 (point, scalar) pairs, the shape of one width-4096 layer's commitment:
+  * zk_msm_batch with FULL-WIDTH (uniform 255-bit) scalars, and
+  * zk_commit with quantised-weight scalars (|w| < 2^13: what Commitment::commit sees, commitment.cu:29-41),
+HIP-event timed, window width c = 6 .. 16 (0 = the library's choice).  Prints a table; --json writes it as JSON."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from oracle_free_gen import generator_jac  # noqa: E402
+from zkdl_amd.capi import MSM_PIPPENGER, Zk  # noqa: E402
+
+
+def main():
+    zk = Zk(0)
+    zk.set_msm_mode(MSM_PIPPENGER)
+    zk.seed(11)
+    n, q = 4096, 4096
+    gens = zk.gens(zk.g1_mul(zk.g1_fill(n, generator_jac()), zk.fr_random(n)))
+    full = zk.fr_random(n * q)
+    small = zk.fr_mont(zk.fr_random_int(n * q, 13))
+    rows = []
+    ref_full = ref_small = None
+    for c in [0] + list(range(6, 17)):
+        zk.set_msm_window(c)
+        rec = {"window": c}
+        for name, fn in (("fullwidth_msm_batch", lambda: zk.msm_batch(gens, full)), ("quantised_commit", lambda: zk.commit(gens, small))):
+            out = fn()                      # builds this width's window table, warms the pools
+            zk.sync()
+            zk.timer_start()
+            out = fn()
+            ms = zk.timer_stop_ms()
+            rec[name + "_ms"] = ms
+            rec[name + "_mops"] = n * q / ms / 1e3
+            aff, inf = zk.g1_to_affine(out.view(0, 64))          # every width must give the same group elements
+            key = (aff.tobytes(), inf.tobytes())
+            if name.startswith("full"):
+                ref_full = ref_full or key
+                assert key == ref_full, "window %d changes the MSM result" % c
+            else:
+                ref_small = ref_small or key
+                assert key == ref_small, "window %d changes the commitment" % c
+            del out
+        rows.append(rec)
+        print("c=%2d   full-width 2^24 pairs: %8.2f ms  %7.1f Mpairs/s     quantised commit: %7.2f ms  %7.1f Mpairs/s" %
+              (c, rec["fullwidth_msm_batch_ms"], rec["fullwidth_msm_batch_mops"], rec["quantised_commit_ms"], rec["quantised_commit_mops"]), flush=True)
+    if "--json" in sys.argv:
+        json.dump({"pairs": n * q, "n_gens": n, "rows": q, "sweep": rows}, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
+    zk.close()
+
+
+if __name__ == "__main__":
+    main()
