@@ -271,3 +271,49 @@ def test_deep4096_slice_verifies_and_2p24_commit_is_linear(zk):
         aw, iw = zk.g1_to_affine(zk.commit(gens, w))
         assert eq(aw, a3) and eq(iw, i3), window
     zk.set_msm_window(0)
+
+
+def test_mlp18m_batch1_whole_proof_matches_oracle(zk, oracle):
+    """BASELINE configs[0] == configs[1]: the WHOLE default model (model.py's 784-1000-1773x5-1124-1000, 18.2M parameters)
+    at batch 1, proved by the CPU oracle (the restatement of the reference algorithm: its scalar path) and by the HIP path on
+    the same quantised weights, generators, commitments and challenges: inference output, every Fr transcript value bit for bit,
+    every G1 value in affine-canonical form.  (The commitments are inputs here -- the literal 26M-scalar-mul commit is hours on
+    a CPU; commit parity is covered at small sizes and by linearity / window invariance at 2^24 pairs.)"""
+    import bench
+    from zkdl_amd.capi import Transcript
+    dims, batch = bench.WORKLOADS["mlp18m_b1"]
+    wl = bench.Workload(zk, dims, batch, seed=8)
+    sh, L = wl.shapes, len(wl.shapes)
+    chal = wl.challenges(0)
+    tr = Transcript(zk)
+    wl.prove(chal, tr)
+    fr_g, _ = tr.read()
+    aff_g, inf_g = tr.read_affine()
+    # the oracle's run on the downloaded inputs
+    W = [fc.weights().download() for fc in wl.fcs]
+    gens = [g.points().download() for g in wl.gens]
+    coms = [fc.com().download() for fc in wl.fcs]
+    X = wl.X.download()
+    Z, A, aux = [], [], []
+    cur = X
+    for i in range(L - 1):
+        z = oracle.fc_forward(cur, W[i], 1, sh[i]["in_p"], sh[i]["out_p"])
+        a, sign, mag, rem = oracle.relu_forward(z)
+        assert eq(z, wl.Z[i].download()) and eq(a, wl.A[i].download())
+        Z.append(z); A.append(a); aux.append((sign, mag, rem))
+        cur = a
+    Yhat = oracle.fr_unmont(oracle.fc_forward(cur, W[L - 1], 1, sh[L - 1]["in_p"], sh[L - 1]["out_p"]))
+    assert eq(Yhat, wl.Yhat.download())
+    frs, g1s = [], []
+    for kind, i, ch in chal:
+        if kind == "fc":
+            x_in = A[i - 1] if i > 0 else X
+            z_out = Yhat if i == L - 1 else Z[i]
+            f, g = oracle.fc_prove(x_in, z_out, W[i], sh[i]["in_p"], sh[i]["out_p"], gens[i], coms[i], *ch)
+            frs.append(f); g1s.append(g)
+        else:
+            frs.append(oracle.relu_prove(Z[i], A[i], *aux[i], *ch))
+    fr_o, g1_o = np.concatenate(frs), np.concatenate(g1s)
+    assert eq(fr_g, fr_o)
+    aff_o, inf_o = oracle.g1_to_affine(g1_o)
+    assert eq(aff_g, aff_o) and eq(inf_g, inf_o)

@@ -118,3 +118,41 @@ def test_demo_proves_with_hash_derived_challenges_and_verifies(tmp_path):
     # challenges must differ too)
     second = open(os.path.join(d, "challenges.bin"), "rb").read()
     assert len(first) == len(second) and first != second
+
+
+def test_demo_accepts_linear_layers_with_bias(tmp_path, oracle):
+    """SURVEY 8f-3 (loader generalisation): nn.Linear WITH bias.  The loader folds the biases into the matrices through a
+    constant "ones" feature (zkdl_amd/host/demo.cpp: load_model), so the proved, bias-free network computes the biased one:
+    demo.out de-quantises to the float model's output and equals the oracle's quantised forward of the AUGMENTED matrices bit
+    for bit; the proof of the augmented network verifies."""
+    exe = os.path.join(HOST, "demo")
+    if not os.path.exists(exe):
+        pytest.skip("zkdl_amd/host/demo not built (needs LibTorch)")
+    import torch
+    import bigint_model as bm
+    d = str(tmp_path)
+    subprocess.run([sys.executable, "-m", "zkdl_amd.model", "--dims", "6,5,4", "--batch", "3", "--seed", "9", "--bias", "--out-dir", d], check=True, cwd=ROOT)
+    run = subprocess.run([exe, os.path.join(d, "traced_model.pt"), os.path.join(d, "sample_input.pt"), "--seed", "5", "--fs", "--verify"], capture_output=True, text=True, cwd=d, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "Total number of parameters: 59" in run.stdout and "Verification: OK" in run.stdout      # 30 + 5 + 20 + 4
+    vals = [int(x, 16) for x in open(os.path.join(d, "demo.out")).read().strip().strip("[]").split("\n")]
+    assert len(vals) == 4 * 4
+    m = torch.jit.load(os.path.join(d, "traced_model.pt"))
+    ps = [p.detach().numpy() for p in m.parameters()]
+    W0, b0, W1, b1 = ps[0].T.copy(), ps[1], ps[2].T.copy(), ps[3]
+    x = list(torch.jit.load(os.path.join(d, "sample_input.pt")).parameters())[0].detach().numpy()
+    want = np.maximum(x.astype(np.float64) @ W0 + b0, 0) @ W1 + b1
+    for b in range(3):
+        for o in range(4):
+            v = vals[b * 4 + o]
+            v = v - bm.R_MOD if v > bm.R_MOD // 2 else v
+            assert abs(v / 2.0 ** 32 - want[b, o]) < 2e-3
+    # bit-exact: the oracle on the augmented matrices  [[W0, e], [b0, 1]]  and  [[W1], [b1]]  with the ones feature appended to x
+    A0 = np.zeros((7, 6), np.float32); A0[:6, :5] = W0; A0[6, :5] = b0; A0[6, 5] = 1.0
+    A1 = np.zeros((6, 4), np.float32); A1[:5] = W1; A1[5] = b1
+    xa = np.concatenate([x, np.ones((3, 1), np.float32)], axis=1)
+    Wq = [oracle.fr_mont(oracle.float_to_fr(A0, 8, 8)), oracle.fr_mont(oracle.float_to_fr(A1, 8, 4))]
+    X = oracle.fr_mont(oracle.float_to_fr(xa, 4, 8))
+    A, *_ = oracle.relu_forward(oracle.fc_forward(X, Wq[0], 4, 8, 8))
+    Y = oracle.fr_unmont(oracle.fc_forward(A, Wq[1], 4, 8, 4))
+    assert vals == [bm.limbs_to_int(r) for r in Y]

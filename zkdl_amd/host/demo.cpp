@@ -55,7 +55,12 @@ torch::Tensor load_tensor(const string& path) {   // demo.cu:40-46
   return tensor;
 }
 
-vector<zkFC> load_model(const string& model_path, vector<unique_ptr<Commitment>>& generators) {   // demo.cu:48-95
+// demo.cu:48-95, generalised: Linear layers WITH bias are accepted.  The protocol itself has no bias term
+// (zkFC proves Z = X W, zkfc.cu:117-145), so the loader folds the biases into the matrices: every activation carries one extra
+// "ones" feature (1.0, i.e. 2^16 after quantisation), every weight matrix one extra input row holding the bias and -- except the
+// last -- one extra output column [0 .. 0 1]^T that passes the ones feature on (Z = 2^32 there, which the ReLU rescales back to
+// 2^16).  The augmented bias-free network computes exactly the biased one, inside the power-of-two padding wherever in + 1 <= in_p.
+vector<zkFC> load_model(const string& model_path, vector<unique_ptr<Commitment>>& generators, bool& has_bias) {
   vector<zkFC> fcs;
   torch::jit::script::Module m;
   try {
@@ -64,13 +69,34 @@ vector<zkFC> load_model(const string& model_path, vector<unique_ptr<Commitment>>
     std::cerr << "Error loading the model\n";
     exit(-1);
   }
-  uint parameter_count = 0;
+  vector<torch::Tensor> Ws, Bs;
+  has_bias = false;
   for (int i = 0;; ++i) {
     if (!m.hasattr(to_string(i))) break;
-    if (!m.attr(to_string(i)).toModule().hasattr("weight")) continue;
-    auto weight_tensor = m.attr(to_string(i)).toModule().attr("weight").toTensor().t();
+    auto child = m.attr(to_string(i)).toModule();
+    if (!child.hasattr("weight")) continue;
+    Ws.push_back(child.attr("weight").toTensor().t().to(torch::kCPU).to(torch::kFloat32).contiguous());   // [in, out]
+    torch::Tensor b;
+    if (child.hasattr("bias") && child.attr("bias").isTensor()) {
+      b = child.attr("bias").toTensor().to(torch::kCPU).to(torch::kFloat32).contiguous();
+      has_bias = true;
+    }
+    Bs.push_back(b);
+  }
+  uint parameter_count = 0;
+  for (size_t l = 0; l < Ws.size(); ++l) {
+    auto weight_tensor = Ws[l];
+    parameter_count += weight_tensor.numel() + (Bs[l].defined() ? Bs[l].numel() : 0);
+    if (has_bias) {
+      const int64_t in = weight_tensor.size(0), out = weight_tensor.size(1);
+      const bool last = l + 1 == Ws.size();
+      auto aug = torch::zeros({in + 1, out + (last ? 0 : 1)}, torch::kFloat32);
+      aug.narrow(0, 0, in).narrow(1, 0, out).copy_(weight_tensor);
+      if (Bs[l].defined()) aug.narrow(0, in, 1).narrow(1, 0, out).copy_(Bs[l].view({1, out}));
+      if (!last) aug.index_put_({in, out}, 1.0f);
+      weight_tensor = aug.contiguous();
+    }
     int in_dim = weight_tensor.sizes()[0], out_dim = weight_tensor.sizes()[1];
-    parameter_count += in_dim * out_dim;
     DeviceFloats w(weight_tensor);
     generators.emplace_back(new Commitment(1U << ((ceilLog2(in_dim * out_dim) + 1) / 2), G1Jacobian_generator));   // demo.cu:81
     *generators.back() *= FrTensor::random(generators.back()->size);                                               // demo.cu:82
@@ -97,13 +123,15 @@ int main(int argc, char* argv[]) {
   }
   zkdl::challenge_log() = &challenges;
   vector<unique_ptr<Commitment>> generators;
-  vector<zkFC> fcs = load_model(argv[1], generators);
+  bool has_bias = false;
+  vector<zkFC> fcs = load_model(argv[1], generators, has_bias);
   vector<zkReLU> relus(fcs.size() - 1);
   vector<FrTensor> Z_vec, A_vec;
   Z_vec.reserve(fcs.size());
   A_vec.reserve(fcs.size());
 
-  torch::Tensor sample_input = load_tensor(argv[2]);
+  torch::Tensor sample_input = load_tensor(argv[2]).to(torch::kCPU).to(torch::kFloat32);
+  if (has_bias) sample_input = torch::cat({sample_input, torch::ones({sample_input.size(0), 1}, torch::kFloat32)}, 1);   // the "ones" feature
   int batch_size = sample_input.size(0), input_dim = sample_input.size(1);
   DeviceFloats xin(sample_input);
   auto X = zkFC::load_float_gpu_input(batch_size, input_dim, xin.p);

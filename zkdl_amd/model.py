@@ -23,11 +23,11 @@ def save_tensor(t, fn):
     torch.jit.script(m).save(fn)
 
 
-def build(dims, seed):
+def build(dims, seed, bias=False):
     torch.manual_seed(seed)
     layers = []
     for i, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
-        layers.append(nn.Linear(a, b, bias=False))
+        layers.append(nn.Linear(a, b, bias=bias))
         if i + 2 < len(dims):
             layers.append(nn.ReLU())
     return nn.Sequential(*layers).eval()
@@ -38,11 +38,12 @@ def main():
     ap.add_argument("--dims", default=",".join(map(str, DEFAULT_DIMS)))
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--bias", action="store_true", help="Linear layers with bias (the reference's model.py has none; the demo's loader folds them into the matrices)")
     ap.add_argument("--out-dir", default=".")
     args = ap.parse_args()
     dims = [int(x) for x in args.dims.split(",")]
     os.makedirs(args.out_dir, exist_ok=True)
-    model = build(dims, args.seed)
+    model = build(dims, args.seed, args.bias)
     x = torch.randn(args.batch, dims[0])
     with torch.no_grad():
         y = model(x)
