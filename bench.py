@@ -342,6 +342,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "off"], help="oracle timed on a layer subset at the bench's batch size (default), on the whole loop, or not at all")
     ap.add_argument("--no-msm-probe", action="store_true", help="skip the full-width 2^24-pair zk_msm_batch throughput probe")
+    ap.add_argument("--prof-steps", type=int, default=2, help="proofs per event-profiled pass after the timed region (ZKDL_PROF_TRACE=<file> writes their per-launch timeline)")
     ap.add_argument("--inflight", type=int, default=3, help="transcripts rotated by the pipelined loop (proofs whose G1 phase may still be running)")
     ap.add_argument("--serial", action="store_true", help="no worker streams at all: every launch runs alone (the schedule the roofline durations are measured under)")
     ap.add_argument("--msm-window", type=int, default=0, help="force the Pippenger window width (0 = library default)")
@@ -406,7 +407,7 @@ def main():
     pipelined = not args.no_pipeline and not args.serial
     if args.serial:
         zk.set_flag("lanes", 0)
-    nprof = max(1, min(args.steps, 2))
+    nprof = max(1, min(args.steps, args.prof_steps))
     rows = torch.zeros((args.steps + 1, 8), dtype=torch.int64, device="cuda")
     scratch_rows = torch.zeros((max(args.warmup, 1) + 4 * nprof + 8, 8), dtype=torch.int64, device="cuda")
     rows_base, scratch_base = rows.data_ptr(), scratch_rows.data_ptr()

@@ -142,10 +142,12 @@ int zk_g1_to_affine(zk_ctx* ctx, const zk_g1j* a_d, uint32_t n, zk_g1a* out_d, u
 enum { ZK_MSM_LITERAL = 0, ZK_MSM_PIPPENGER = 1 };
 int zk_set_msm_mode(zk_ctx* ctx, int mode);
 int zk_set_msm_window(zk_ctx* ctx, uint32_t window_bits);   /* 0 = automatic */
-/* Scheduling / representation switches, all on by default; none of them changes a transcript value:
+/* Scheduling / representation switches, on by default unless noted; none of them changes a transcript value:
  *   "relu_packed"   ReLU aux sumchecks and partial_me read the packed bits instead of the one-Fr-per-bit tensors
  *   "relu_bytes"    ... and take rounds 0-4 (32-bit words) / 0-3 (16-bit) from weighted byte histograms instead of the
  *                   three-round lookup-table form
+ *   "derive_rounds" (default 0) the opening's round commitments T_1 .. T_{k-1} are derived from T_0, T0_j, T1_j by the folding
+ *                   relation (k^2 - 1 scalar multiplications behind the MSM batch) instead of run as k - 1 full-size MSMs
  *   "batch_layers"  zk_fc_prove / zk_relu_prove record their launches; flush/seal runs them batched across layers
  *   "lanes"         worker streams (the recorder's groups, the G1 streams of zk_transcript_seal); off = one stream
  *   "weights_q16"   layers created while set keep an int16 copy of quantised weights (|w| < 2^15) for the

@@ -368,6 +368,25 @@ def test_msm_window_sweep_gives_same_points(zk, oracle, rng, window):
         zk.set_msm_window(0)
 
 
+def test_derived_round_commitments_equal_the_msm_ones(zk, oracle):
+    """`derive_rounds`: T_1 .. T_{k-1} of every opening from the folding relation (scalar multiplications of T_0, T0_j, T1_j
+    behind the MSM batch) instead of as MSMs -- the same group elements, hence the same affine transcript and the oracle's."""
+    from mlp_util import prove_mlp_gpu, prove_mlp_oracle, synth_mlp
+    from zkdl_amd.capi import MSM_PIPPENGER
+    zk.set_msm_mode(MSM_PIPPENGER)
+    model = synth_mlp(oracle, [16, 32, 24, 8], 4, seed=23)
+    fr_o, g1_o = prove_mlp_oracle(oracle, model)
+    aff_o, inf_o = oracle.g1_to_affine(g1_o)
+    gens = [zk.gens(zk.upload(g)) for g in model["gens"]]
+    try:
+        for flag in (1, 0):
+            zk.set_flag("derive_rounds", flag)
+            fr_g, aff_g, inf_g, _ = prove_mlp_gpu(zk, model, gens_dev=gens)
+            assert eq(fr_g, fr_o) and eq(aff_g, aff_o) and eq(inf_g, inf_o), flag
+    finally:
+        zk.set_flag("derive_rounds", 0)
+
+
 # batch 1 (BASELINE configs[1]): k_bs = 0, partial_me with no challenges is the identity (fr-tensor.cu:370-374, App. D-3)
 @pytest.mark.parametrize("dims,batch", [([6, 5, 4], 3), ([16, 32, 8], 4), ([5, 3], 1), ([12, 20, 9, 7], 1)])
 def test_mlp_prove_pippenger_matches_oracle(zk, oracle, dims, batch):

@@ -150,7 +150,7 @@ int zk_ctx_create(int device, zk_ctx** out) {
     {
       int ng = 2;
       if (const char* e = getenv("ZKDL_G1_STREAMS")) ng = atoi(e);
-      ng = ng < 0 ? 0 : ng > 4 ? 4 : ng;
+      ng = ng < 0 ? 0 : ng > 8 ? 8 : ng;
       ctx->g1_lanes.resize((size_t)ng);
       // The G1 streams are confined to every other compute unit: the bulk MSM accumulation (a whole-chip launch
       // of ~1.7 ms) then cannot take the chip away from the next proof's latency-bound Fr chains.  Measured on
@@ -561,6 +561,7 @@ int zk_set_flag(zk_ctx* ctx, const char* name, int value) {
   CHECK_HOST(ctx, name);
   if (!strcmp(name, "relu_packed")) ctx->relu_packed = value != 0;
   else if (!strcmp(name, "relu_bytes")) ctx->relu_bytes = value != 0;
+  else if (!strcmp(name, "derive_rounds")) ctx->derive_rounds = value != 0;
   else if (!strcmp(name, "lanes")) ctx->lanes_enabled = value != 0;
   else if (!strcmp(name, "batch_layers")) ctx->batch_layers = value != 0;
   else if (!strcmp(name, "weights_q16")) ctx->flag_q16 = value != 0;

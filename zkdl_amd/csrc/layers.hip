@@ -296,7 +296,9 @@ int zk_transcript::seal(uint64_t* out8_d) {
   ctx->stream = g.stream;
   ctx->cur_pool = &g.pool;
   int rc = ZK_OK;
-  if (!queue.jobs.empty()) rc = msm_run_jobs(ctx, queue.jobs, queue.c);
+  static const bool skip_g1 = getenv("ZKDL_EXPERIMENT_SKIP_G1") != nullptr;  // timing experiments only: the G1 values are garbage then
+  if (!queue.jobs.empty() && !skip_g1) rc = msm_run_jobs(ctx, queue.jobs, queue.c);
+  if (rc == ZK_OK && !skip_g1) rc = msm_run_derives(ctx, queue.derives);
   if (rc == ZK_OK && n_g1 > n_g1_final && ctx->msm_mode == ZK_MSM_PIPPENGER) rc = g1_canonicalise_dev(ctx, g1_d + n_g1_final, (uint32_t)(n_g1 - n_g1_final));
   if (rc == ZK_OK && out8_d) rc = transcript_digest_dev(ctx, fr_d, n_fr, g1_d, n_g1, nullptr, out8_d);
   (void)hipEventRecord(sealed_ev, g.stream);
@@ -307,6 +309,7 @@ int zk_transcript::seal(uint64_t* out8_d) {
   ctx->cur_pool = &ctx->main_pool;
   n_g1_final = n_g1;
   queue.jobs.clear();
+  queue.derives.clear();
   queue.c = 0;
   for (auto& b : queue.keep) deferred_keep.push_back(std::move(b));
   queue.keep.clear();
@@ -387,12 +390,14 @@ int fc_forward(zk_ctx* ctx, const zk_fc* fc, const Fr* x, uint32_t xn, Fr* z) {
 struct ProveGuard {
   zk_ctx* ctx;
   zk_transcript* tr;
-  size_t n_fr, n_g1, chains, jobs, keep;
-  ProveGuard(zk_ctx* c, zk_transcript* t) : ctx(c), tr(t), n_fr(t->n_fr), n_g1(t->n_g1), chains(t->rec.chains.size()), jobs(t->queue.jobs.size()), keep(t->queue.keep.size()) {}
+  size_t n_fr, n_g1, chains, jobs, keep, derives;
+  ProveGuard(zk_ctx* c, zk_transcript* t)
+      : ctx(c), tr(t), n_fr(t->n_fr), n_g1(t->n_g1), chains(t->rec.chains.size()), jobs(t->queue.jobs.size()), keep(t->queue.keep.size()), derives(t->queue.derives.size()) {}
   int finish(int rc) {
     if (rc == ZK_OK) return rc;
     rec_rollback(ctx, &tr->rec, chains);
     if (tr->queue.jobs.size() > jobs) tr->queue.jobs.resize(jobs);
+    if (tr->queue.derives.size() > derives) tr->queue.derives.resize(derives);
     while (tr->queue.keep.size() > keep) tr->queue.keep.pop_back();
     tr->n_fr = n_fr;
     tr->n_g1 = n_g1;

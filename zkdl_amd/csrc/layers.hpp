@@ -17,8 +17,14 @@ struct MsmJobHost {  // one pending MSM: *out = sum_j mags[j] * base_j over tabl
   G1J* out;
   uint32_t W;
 };
+struct DeriveJobHost {  // T_1 .. T_{k-1} of one me_open, derived from T_0 and the T0_j / T1_j behind the MSM batch (msm.hip)
+  G1J* proof;            // the me_open's 3k+1 transcript slots
+  const Fr* coef;        // k^2 - 1 raw scalars (k_mo_derive_coef)
+  uint32_t k;
+};
 struct MsmQueue {  // MSMs enqueued by the provers, executed together by msm_flush()
   std::vector<MsmJobHost> jobs;
+  std::vector<DeriveJobHost> derives;
   std::vector<DBuf<Fr>> keep;  // prepared scalars, alive until the flush
   uint32_t c = 0;
 };
@@ -87,7 +93,8 @@ int gens_create(zk_ctx* ctx, const G1J* gens_d, uint32_t n, bool copy, zk_gens**
 void gens_destroy(zk_gens* g);
 int gens_table(zk_ctx* ctx, zk_gens* g, uint32_t c, uint32_t W, const G1Table** out);
 int msm_batch_dev(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_unmont, bool probe_bits, G1J* out);
-int msm_enqueue(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_unmont, bool probe_bits, G1J* out, MsmQueue* queue);
+int msm_enqueue(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_unmont, bool probe_bits, G1J* out, MsmQueue* queue, const uint32_t* out_idx = nullptr);
+int msm_run_derives(zk_ctx* ctx, const std::vector<DeriveJobHost>& derives);
 int msm_flush(zk_ctx* ctx, MsmQueue* queue);
 int msm_run_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs, uint32_t c);
 int g1_canonicalise_dev(zk_ctx* ctx, G1J* pts, uint32_t n);

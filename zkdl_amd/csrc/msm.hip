@@ -598,7 +598,7 @@ int msm_run_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs, uint32_t c) 
 }
 
 // prepare q scalar rows over the generator set g and append them as jobs (out[i] receives MSM i)
-int msm_enqueue(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_unmont, bool probe_bits, G1J* out, MsmQueue* queue) {
+int msm_enqueue(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_unmont, bool probe_bits, G1J* out, MsmQueue* queue, const uint32_t* out_idx) {
   const uint32_t n = g->n;
   if (q == 0) return ZK_OK;
   uint64_t total = (uint64_t)q * n;
@@ -620,7 +620,7 @@ int msm_enqueue(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_
   queue->c = c;
   const G1Table* T = nullptr;
   ZK_TRY(gens_table(ctx, g, c, W, &T));
-  for (uint32_t i = 0; i < q; i++) queue->jobs.push_back(MsmJobHost{T, mags.get() + (uint64_t)i * n, out + i, W});
+  for (uint32_t i = 0; i < q; i++) queue->jobs.push_back(MsmJobHost{T, mags.get() + (uint64_t)i * n, out + (out_idx ? out_idx[i] : i), W});
   queue->keep.push_back(std::move(mags));
   return ZK_OK;
 }
@@ -628,7 +628,9 @@ int msm_enqueue(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_
 int msm_flush(zk_ctx* ctx, MsmQueue* queue) {  // on the current stream; releases the prepared scalars
   if (queue->jobs.empty()) return ZK_OK;
   int rc = msm_run_jobs(ctx, queue->jobs, queue->c);
+  if (rc == ZK_OK) rc = msm_run_derives(ctx, queue->derives);
   queue->jobs.clear();
+  queue->derives.clear();
   queue->keep.clear();  // stream-ordered frees: safe behind the kernels just enqueued
   queue->c = 0;
   return rc;
@@ -664,12 +666,13 @@ __device__ __forceinline__ void k_mo_coef(uint32_t zk_nblk, const Fr* __restrict
 }
 // scal[(3r + e)*n + i] for rounds r < k, e in {T, T0, T1}; scal[3k*n + i] = unmont(C_k[i]).
 // S holds the folded scalar tensors back to back: S_r at offset 2n - (2n >> r).
-__device__ __forceinline__ void k_mo_scalars(uint32_t zk_nblk, const Fr* __restrict__ C, const Fr* __restrict__ S, uint32_t n, uint32_t k, Fr* __restrict__ scal) {
+// compact != 0 (derived rounds): rows are [T_0][T0_0, T1_0][T0_1, T1_1] .. [final]: T_r, r >= 1, is not an MSM
+__device__ __forceinline__ void k_mo_scalars(uint32_t zk_nblk, const Fr* __restrict__ C, const Fr* __restrict__ S, uint32_t n, uint32_t k, Fr* __restrict__ scal, uint32_t compact) {
   uint64_t total = (uint64_t)(k + 1) * n;
   for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)zk_nblk * blockDim.x) {
     uint32_t r = (uint32_t)(g / n), i = (uint32_t)(g - (uint64_t)r * n);
     if (r == k) {
-      scal[(uint64_t)3 * k * n + i] = fr_unmont(C[(1u << k) - 1u + i]);
+      scal[(uint64_t)(compact ? 2 * k + 1 : 3 * k) * n + i] = fr_unmont(C[(1u << k) - 1u + i]);
       continue;
     }
     uint32_t j = i >> r, l = i & ((1u << r) - 1u);
@@ -677,10 +680,104 @@ __device__ __forceinline__ void k_mo_scalars(uint32_t zk_nblk, const Fr* __restr
     const Fr* Sr = S + (2ull * n - ((2ull * n) >> r));
     Fr zero = fr_zero();
     // mont_mul(C~, s^) = C * s^ mod r as an integer: the MSM scalar of original generator i
-    scal[(uint64_t)(3 * r + 0) * n + i] = fr_mul(cf, Sr[j]);
-    scal[(uint64_t)(3 * r + 1) * n + i] = (j & 1u) ? fr_mul(cf, Sr[j - 1]) : zero;  // T0 = sum g_{2j+1} * s_{2j}
-    scal[(uint64_t)(3 * r + 2) * n + i] = (j & 1u) ? zero : fr_mul(cf, Sr[j + 1]);  // T1 = sum g_{2j} * s_{2j+1}
+    if (!compact || r == 0) scal[(uint64_t)(3 * r + 0) * n + i] = fr_mul(cf, Sr[j]);
+    const uint32_t r0 = compact ? 2 * r + 1 : 3 * r + 1;
+    scal[(uint64_t)r0 * n + i] = (j & 1u) ? fr_mul(cf, Sr[j - 1]) : zero;        // T0 = sum g_{2j+1} * s_{2j}
+    scal[(uint64_t)(r0 + 1) * n + i] = (j & 1u) ? zero : fr_mul(cf, Sr[j + 1]);  // T1 = sum g_{2j} * s_{2j+1}
   }
+}
+
+// ---- derived round commitments.  T_r is the commitment of round r's scalars under round r's generators, so the verifier's
+// folding relation  T_{r+1} = a_r T_r + b_r T0_r + c_r T1_r  (a = u(1-u), b = (1-u)^2, c = u^2, u = unmont(challenge)) holds for the
+// values the reference computes (zk_verify_fc checks exactly this).  Unrolled,
+//     T_r = (prod_{i<r} a_i) T_0 + sum_{j<r} (prod_{j<i<r} a_i) (b_j T0_j + c_j T1_j),
+// a combination of 2r + 1 points that the MSM batch produces anyway.  So only T_0, the T0_r / T1_r and the final generator run
+// as MSMs (2k + 2 of the 3k + 1: the T_r are the FULL-size ones, 42 % of all (point, window) items of a proof), and T_1 .. T_{k-1}
+// are k^2 - 1 scalar multiplications behind the batch: about 4 ms of latency on a handful of waves, i.e. a longer G1 phase under the
+// following proofs' Fr phases, for a fifth less vector work per proof.  Same group elements as the reference's T_r.
+// coef[r^2 - 1 + s], 1 <= r < k: s = 0 -> T_0; s = 1 + 2j -> T0_j; s = 2 + 2j -> T1_j (j < r); raw integers
+__device__ __forceinline__ void k_mo_derive_coef(uint32_t zk_nblk, const Fr* __restrict__ u, uint32_t k, Fr* __restrict__ coef) {
+  const uint32_t total = k * k - 1;
+  for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += zk_nblk * blockDim.x) {
+    uint32_t r = 1;
+    while ((r + 1) * (r + 1) - 1 <= idx) r++;
+    const uint32_t s = idx - (r * r - 1);
+    const Fr one = fr_one();
+    Fr acc = one;
+    uint32_t from = 0;  // product of a_i over from <= i < r
+    if (s > 0) {
+      const uint32_t j = (s - 1) >> 1;
+      const Fr uj = u[j], nj = fr_sub(one, uj);
+      acc = (s & 1u) ? fr_mul(nj, nj) : fr_mul(uj, uj);
+      from = j + 1;
+    }
+    for (uint32_t i = from; i < r; i++) {
+      const Fr ui = u[i];
+      acc = fr_mul(acc, fr_mul(ui, fr_sub(one, ui)));
+    }
+    coef[idx] = fr_unmont(acc);
+  }
+}
+struct DeriveJob {
+  G1J* proof;
+  const Fr* coef;
+  uint32_t k, lane_off;
+};
+// one lane per (job, r, s): tmp[lane] = coef * point
+__global__ void __launch_bounds__(64) k_derive_mul(const DeriveJob* __restrict__ jobs, uint32_t nj, uint32_t total, G1J* __restrict__ tmp) {
+  const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lane >= total) return;
+  uint32_t q = 0;
+  while (q + 1 < nj && jobs[q + 1].lane_off <= lane) q++;
+  const DeriveJob job = jobs[q];
+  const uint32_t idx = lane - job.lane_off;
+  uint32_t r = 1;
+  while ((r + 1) * (r + 1) - 1 <= idx) r++;
+  const uint32_t s = idx - (r * r - 1);
+  const uint32_t src = s == 0 ? 0u : 3u * ((s - 1) >> 1) + ((s & 1u) ? 1u : 2u);
+  tmp[lane] = g1_mul_naive(job.proof[src], job.coef[idx]);
+}
+// one lane per (job, r): proof[3r] = sum of its 2r + 1 products
+__global__ void __launch_bounds__(64) k_derive_sum(const DeriveJob* __restrict__ jobs, uint32_t nj, uint32_t nseg, const uint32_t* __restrict__ seg_job, const G1J* __restrict__ tmp) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nseg) return;
+  const uint32_t q = seg_job[2 * t], r = seg_job[2 * t + 1];
+  const DeriveJob job = jobs[q];
+  const G1J* p = tmp + job.lane_off + (r * r - 1);
+  G1J acc = p[0];
+  for (uint32_t s = 1; s < 2 * r + 1; s++) acc = g1_add(acc, p[s]);
+  job.proof[3 * r] = acc;
+}
+int msm_run_derives(zk_ctx* ctx, const std::vector<DeriveJobHost>& derives) {
+  if (derives.empty()) return ZK_OK;
+  std::vector<DeriveJob> jobs;
+  std::vector<uint32_t> seg;
+  uint32_t total = 0;
+  for (const auto& d : derives) {
+    if (d.k < 2) continue;
+    for (uint32_t r = 1; r < d.k; r++) {
+      seg.push_back((uint32_t)jobs.size());
+      seg.push_back(r);
+    }
+    jobs.push_back(DeriveJob{d.proof, d.coef, d.k, total});
+    total += d.k * d.k - 1;
+  }
+  if (jobs.empty()) return ZK_OK;
+  const uint32_t nj = (uint32_t)jobs.size(), nseg = (uint32_t)seg.size() / 2;
+  ZK_ALLOC(ctx, djobs, DeriveJob, nj);
+  ZK_ALLOC(ctx, dseg, uint32_t, seg.size());
+  ZK_ALLOC(ctx, tmp, G1J, total);
+  {
+    void* st = ctx->stage_put(jobs.data(), jobs.size() * sizeof(DeriveJob));
+    if (!st) return ctx->fail(ZK_ERR_ALLOC, "pinned staging exhausted");
+    ZK_TRY(dev_copy(ctx, djobs.get(), st, (jobs.size() * sizeof(DeriveJob) + 15) & ~(size_t)15));
+    st = ctx->stage_put(seg.data(), seg.size() * 4);
+    if (!st) return ctx->fail(ZK_ERR_ALLOC, "pinned staging exhausted");
+    ZK_TRY(dev_copy(ctx, dseg.get(), st, (seg.size() * 4 + 15) & ~(size_t)15));
+  }
+  ZK_LAUNCH(ctx, "msm_derive", 320ull * total, k_derive_mul, dim3((total + 63) / 64), dim3(64), 0, (const DeriveJob*)djobs.get(), nj, total, tmp.get());
+  ZK_LAUNCH(ctx, "msm_derive", 144ull * total, k_derive_sum, dim3((nseg + 63) / 64), dim3(64), 0, (const DeriveJob*)djobs.get(), nj, nseg, (const uint32_t*)dseg.get(), (const G1J*)tmp.get());
+  return ZK_OK;
 }
 
 int me_open_flat_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d, MsmQueue* queue) {
@@ -698,10 +795,28 @@ int me_open_flat_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32
   uint32_t ncoef = (2u << k) - 1u;
   ZK_ALLOC(ctx, C, Fr, ncoef);
   ZK_LAUNCHB(ctx, "me_open_scalars", 32ull * ncoef, 256, k_mo_coef, dim3((ncoef + 255) / 256), 0, u_d, k, C.get());
-  uint32_t q = 3 * k + 1;
+  const bool derive = queue && ctx->derive_rounds && k >= 2;
+  uint32_t q = derive ? 2 * k + 2 : 3 * k + 1;
   ZK_ALLOC(ctx, scal, Fr, (size_t)q * n);
   ZK_LAUNCHB(ctx, "me_open_scalars", 32ull * q * n, 256, k_mo_scalars, dim3(stream_grid((uint64_t)(k + 1) * n)), 0, (const Fr*)C.get(), (const Fr*)S.get(), n, k,
-            scal.get());
+            scal.get(), derive ? 1u : 0u);
+  if (derive) {
+    // deferred batch: T_0, every T0_r / T1_r and the final generator as MSMs; T_1 .. T_{k-1} derived behind the batch
+    std::vector<uint32_t> rows;
+    rows.push_back(0);
+    for (uint32_t r = 0; r < k; r++) {
+      rows.push_back(3 * r + 1);
+      rows.push_back(3 * r + 2);
+    }
+    rows.push_back(3 * k);
+    ZK_TRY(msm_enqueue(ctx, g, scal.get(), q, /*do_unmont=*/false, /*probe_bits=*/false, proof_d, queue, rows.data()));
+    DBuf<Fr> coef;
+    if (!coef.alloc(ctx, (size_t)k * k)) return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: derive coefficients");
+    ZK_LAUNCHB(ctx, "me_open_scalars", 32ull * k * k, 64, k_mo_derive_coef, dim3((k * k + 63) / 64), 0, u_d, k, coef.get());
+    queue->derives.push_back(DeriveJobHost{proof_d, coef.get(), k});
+    queue->keep.push_back(std::move(coef));
+    return ZK_OK;
+  }
   if (queue) return msm_enqueue(ctx, g, scal.get(), q, /*do_unmont=*/false, /*probe_bits=*/false, proof_d, queue);
   return msm_batch_dev(ctx, g, scal.get(), q, /*do_unmont=*/false, /*probe_bits=*/false, proof_d);
 }
