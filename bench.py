@@ -394,6 +394,9 @@ def main():
     zk.set_msm_mode(MSM_PIPPENGER if args.msm == "pippenger" else MSM_LITERAL)
     if args.msm_window:
         zk.set_msm_window(args.msm_window)
+    for kv in os.environ.get("ZKDL_BENCH_FLAGS", "").split(","):       # e.g. ZKDL_BENCH_FLAGS=derive_rounds=1,relu_bytes=0 (A/B runs)
+        if "=" in kv:
+            zk.set_flag(kv.split("=")[0], int(kv.split("=")[1]))
     dims, batch = WORKLOADS[args.workload]
     if args.mode == "shard":
         return run_sharded(args, zk, dims, batch, rank, world, dist)

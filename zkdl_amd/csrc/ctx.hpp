@@ -140,6 +140,7 @@ struct zk_ctx {
     main_pool.free_lists.clear();
     for (auto& l : lanes) l.pool.free_lists.clear();
     for (auto& g : g1_lanes) g.pool.free_lists.clear();
+    for (auto& g : tail_lanes) g.pool.free_lists.clear();
   }
 
   // ---- lanes: worker streams for independent per-layer proofs (zk_fc_prove / zk_relu_prove).
@@ -158,6 +159,11 @@ struct zk_ctx {
   // (round-robin), so the latency-bound tail of one proof's G1 phase overlaps the next one's accumulation
   std::vector<Lane> g1_lanes;
   uint32_t next_g1 = 0;
+  // tail streams: the latency-bound end of a sealed proof's G1 phase (derived round commitments, the canonicalising inversion,
+  // the digest: a handful of waves for milliseconds) runs here, behind an event of the G1 stream, so that the G1 streams -- which
+  // carry the chip-filling MSM kernels -- are free for the next proof's batch.  Empty: everything stays on the G1 stream.
+  std::vector<Lane> tail_lanes;
+  uint32_t next_tail = 0;
   hipStream_t main_stream = nullptr;
   hipEvent_t fork_ev = nullptr;
   uint32_t layer_serial = 0;  // next zk_fc / zk_relu serial number (their lane hint)
@@ -175,11 +181,14 @@ struct zk_ctx {
   void wait_g1(hipStream_t st) {
     for (auto& g : g1_lanes)
       if (g.dirty) (void)hipStreamWaitEvent(st, g.done, 0);
+    for (auto& g : tail_lanes)
+      if (g.dirty) (void)hipStreamWaitEvent(st, g.done, 0);
   }
   void join_all() {
     join_lanes();
     wait_g1(main_stream);
     for (auto& g : g1_lanes) g.dirty = false;
+    for (auto& g : tail_lanes) g.dirty = false;
   }
 
   int fail(int code, const std::string& msg) {

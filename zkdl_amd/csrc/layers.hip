@@ -298,12 +298,29 @@ int zk_transcript::seal(uint64_t* out8_d) {
   int rc = ZK_OK;
   static const bool skip_g1 = getenv("ZKDL_EXPERIMENT_SKIP_G1") != nullptr;  // timing experiments only: the G1 values are garbage then
   if (!queue.jobs.empty() && !skip_g1) rc = msm_run_jobs(ctx, queue.jobs, queue.c);
+  // the latency-bound tail (derived round commitments, canonicalisation, digest) moves to a tail stream when there is one
+  zk_ctx::Lane* tail = ctx->tail_lanes.empty() ? nullptr : &ctx->tail_lanes[ctx->next_tail++ % ctx->tail_lanes.size()];
+  hipStream_t fin = g.stream;
+  if (tail) {
+    (void)hipEventRecord(g.done, g.stream);
+    g.dirty = true;
+    (void)hipStreamWaitEvent(tail->stream, g.done, 0);
+    ctx->stream = tail->stream;
+    ctx->cur_pool = &tail->pool;
+    fin = tail->stream;
+    sealed_stream = tail->stream;
+  }
   if (rc == ZK_OK && !skip_g1) rc = msm_run_derives(ctx, queue.derives);
   if (rc == ZK_OK && n_g1 > n_g1_final && ctx->msm_mode == ZK_MSM_PIPPENGER) rc = g1_canonicalise_dev(ctx, g1_d + n_g1_final, (uint32_t)(n_g1 - n_g1_final));
   if (rc == ZK_OK && out8_d) rc = transcript_digest_dev(ctx, fr_d, n_fr, g1_d, n_g1, nullptr, out8_d);
-  (void)hipEventRecord(sealed_ev, g.stream);
-  (void)hipEventRecord(g.done, g.stream);
-  g.dirty = true;
+  (void)hipEventRecord(sealed_ev, fin);
+  if (tail) {
+    (void)hipEventRecord(tail->done, tail->stream);
+    tail->dirty = true;
+  } else {
+    (void)hipEventRecord(g.done, g.stream);
+    g.dirty = true;
+  }
   sealed = true;
   ctx->stream = ctx->main_stream;
   ctx->cur_pool = &ctx->main_pool;

@@ -1,6 +1,7 @@
 // zkdl_amd/csrc/recorder.hip -- deferred execution of recorded launch chains, zipped across layers
 // (see launch.hpp for the why).  Everything here is host code.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "ctx.hpp"
@@ -175,7 +176,8 @@ int rec_execute(zk_ctx* ctx, Recorder* r) {
     }
   }
   auto stream_of = [&](uint32_t g) -> hipStream_t { return (g == 0 || !fan_out) ? home : ctx->lanes[(g - 1) % ctx->lanes.size()].stream; };
-  for (size_t i = 0; i < batches.size() && rc == ZK_OK; i++) {
+  static const bool skip_fr = getenv("ZKDL_EXPERIMENT_SKIP_FR") != nullptr;  // timing experiments only: nothing recorded is launched
+  for (size_t i = 0; i < batches.size() && rc == ZK_OK && !skip_fr; i++) {
     const Batch& b = batches[i];
     ctx->stream = stream_of(b.group);
     int lr;
