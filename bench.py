@@ -342,8 +342,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "off"], help="oracle timed on a layer subset at the bench's batch size (default), on the whole loop, or not at all")
     ap.add_argument("--no-msm-probe", action="store_true", help="skip the full-width 2^24-pair zk_msm_batch throughput probe")
+    ap.add_argument("--spinup-ms", type=float, default=400.0, help="untimed proofs before the W warm-up steps until this much wall time has passed: the first process on a "
+                    "fresh box otherwise runs its first ~100 ms 12 %% slow (GPU power state); 0 disables")
     ap.add_argument("--prof-steps", type=int, default=2, help="proofs per event-profiled pass after the timed region (ZKDL_PROF_TRACE=<file> writes their per-launch timeline)")
-    ap.add_argument("--inflight", type=int, default=3, help="transcripts rotated by the pipelined loop (proofs whose G1 phase may still be running)")
+    ap.add_argument("--inflight", type=int, default=5, help="transcripts rotated by the pipelined loop (proofs whose G1 phase may still be running)")
+    ap.add_argument("--no-derive", action="store_true", help="run every round commitment T_r of the openings as an MSM (library default) instead of deriving T_1.. from the "
+                    "folding relation behind the MSM batch (the throughput configuration: -31 %% msm_accum work, a ~6 ms longer G1 phase per proof)")
     ap.add_argument("--serial", action="store_true", help="no worker streams at all: every launch runs alone (the schedule the roofline durations are measured under)")
     ap.add_argument("--msm-window", type=int, default=0, help="force the Pippenger window width (0 = library default)")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every proof on the main stream (no overlap of proof i's G1 phase with proof i+1's Fr phase)")
@@ -394,6 +398,8 @@ def main():
     zk.set_msm_mode(MSM_PIPPENGER if args.msm == "pippenger" else MSM_LITERAL)
     if args.msm_window:
         zk.set_msm_window(args.msm_window)
+    derive = not args.no_derive and args.msm == "pippenger"
+    zk.set_flag("derive_rounds", 1 if derive else 0)
     for kv in os.environ.get("ZKDL_BENCH_FLAGS", "").split(","):       # e.g. ZKDL_BENCH_FLAGS=derive_rounds=1,relu_bytes=0 (A/B runs)
         if "=" in kv:
             zk.set_flag(kv.split("=")[0], int(kv.split("=")[1]))
@@ -431,8 +437,21 @@ def main():
         if world > 1:
             dist.barrier()
 
+    t_spin = time.perf_counter()
+    n_spin = 0
+    while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
+        step(-100000 - n_spin, scratch_base)
+        n_spin += 1
+        if n_spin % 8 == 0:
+            zk.sync()                            # do not let the host run ahead of the device during the spin-up
+    zk.sync()
     for i in range(args.warmup):
+        # the warm-up also runs one proof in the drain configuration (see below), so that the allocator pools hold blocks of both shapes
+        if derive and args.warmup >= 2 and i == args.warmup - 2:
+            zk.lib.zk_set_flag(zk.ctx, b"derive_rounds", 0)
         step(-1 - i, scratch_base + 64 * i)
+        if derive:
+            zk.lib.zk_set_flag(zk.ctx, b"derive_rounds", 1)
     if world > 1:                                # warm the communicator outside the timed region
         dist.all_reduce(scratch_rows[-1], op=dist.ReduceOp.SUM)
     barrier()
@@ -441,8 +460,14 @@ def main():
     gc.collect()
     gc.freeze()
     gc.disable()
+    # Derived round commitments trade a longer G1 phase per proof (~11 ms instead of ~5) for less vector work: worth it while there
+    # are later proofs to hide it under.  The LAST proofs of the run have none, so they take the short G1 phase (every T_r as an MSM):
+    # the pipeline then drains in one MSM chain instead of two.
+    drain_from = args.steps - 3 if derive else args.steps
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if i == drain_from:
+            zk.lib.zk_set_flag(zk.ctx, b"derive_rounds", 0)
         step(i, rows_base + 64 * i)
     t_enq = time.perf_counter() - t0          # host time to enqueue K steps (no device wait inside)
     zk.sync()                                 # all G1 streams joined: every row is final
@@ -452,6 +477,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    zk.set_flag("derive_rounds", 1 if derive else 0)
     per_rank_ms = [elapsed * 1e3 / max(args.steps, 1)]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -511,7 +537,8 @@ def main():
     # MSM items of one proof: the launch is sized for n * W slots per job (its `bytes`), but T0_r / T1_r only touch every other
     # generator (their other scalars are zero and are dropped by the sort): per layer 2 k_lo n + n (T, T0, T1 of every round, the
     # final generator) + m (com(u_hi)) nonzero full-width scalars, 26 ten-bit windows each
-    real_pairs = sum(2 * ceil_log2(s_["n_gens"]) * s_["n_gens"] + s_["n_gens"] + s_["m"] for s_ in wl.shapes)
+    # (with derived round commitments the k - 1 full-size T_r MSMs are gone: (k + 2) n + m)
+    real_pairs = sum(((ceil_log2(s_["n_gens"]) + 2) if derive else (2 * ceil_log2(s_["n_gens"]) + 1)) * s_["n_gens"] + s_["m"] for s_ in wl.shapes)
     if "msm_accum" in prof:
         slots = prof["msm_accum"]["bytes"] / 100.0 / max(prof["msm_accum"]["launches"], 1)
         items = min(slots, real_pairs * 26.0) if args.msm == "pippenger" and not args.msm_window else slots
@@ -546,7 +573,7 @@ def main():
            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (Fr) / u32x12 (Fp) limbs",
            "data": "synthetic",
            "config": {"workload": args.workload, "dims": dims, "batch_per_gpu": batch, "parallelism": "independent proofs per rank, one RCCL all-reduce of the run aggregate",
-                      "msm": args.msm},
+                      "msm": args.msm, "derive_rounds": bool(derive), "inflight": args.inflight},
            "ms_per_proof": ms_per_step, "per_rank_ms_per_proof": per_rank_ms, "collective_world_size": (dist.get_world_size() if world > 1 else 1),
            "collective_backend": (dist.get_backend() if world > 1 else None),
            "host_enqueue_ms_per_step": t_enq * 1e3 / max(args.steps, 1), "aggregate_fr": hex(aggregate), "setup": wl.info, "roofline": roofline, "kernels": kernels,

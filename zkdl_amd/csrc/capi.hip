@@ -152,7 +152,7 @@ int zk_ctx_create(int device, zk_ctx** out) {
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     int prio = g1_prio < 0 ? least : g1_prio > 0 ? greatest : (least + greatest) / 2;
     {
-      int ng = 2;
+      int ng = 4;  // 2 suffice without derived round commitments; with them a sealed proof's G1 phase is ~11 ms long (sched sweeps: DESIGN.md sec.10)
       if (const char* e = getenv("ZKDL_G1_STREAMS")) ng = atoi(e);
       ng = ng < 0 ? 0 : ng > 8 ? 8 : ng;
       ctx->g1_lanes.resize((size_t)ng);
@@ -589,11 +589,16 @@ int zk_set_msm_mode(zk_ctx* ctx, int mode) {
   return ZK_OK;
 }
 int zk_set_flag(zk_ctx* ctx, const char* name, int value) {
-  CHECK_CTX(ctx);
+  CHECK_CTX_NOJOIN(ctx);
   CHECK_HOST(ctx, name);
+  if (!strcmp(name, "lanes") || !strcmp(name, "batch_layers")) {  // these change how recorded work runs: settle what is pending first
+    int src = ctx->settle();
+    if (src != ZK_OK) return src;
+  }
   if (!strcmp(name, "relu_packed")) ctx->relu_packed = value != 0;
   else if (!strcmp(name, "relu_bytes")) ctx->relu_bytes = value != 0;
   else if (!strcmp(name, "derive_rounds")) ctx->derive_rounds = value != 0;
+  else if (!strcmp(name, "pipeline_fr")) ctx->pipeline_fr = value != 0;
   else if (!strcmp(name, "lanes")) ctx->lanes_enabled = value != 0;
   else if (!strcmp(name, "batch_layers")) ctx->batch_layers = value != 0;
   else if (!strcmp(name, "weights_q16")) ctx->flag_q16 = value != 0;
@@ -784,6 +789,7 @@ int zk_transcript_destroy(zk_transcript* tr) {
   if (!tr) return ZK_ERR_ARG;
   tr->ctx->join_lanes();
   (void)tr->flush();
+  zk::rec_release_held(tr->ctx, &tr->rec);
   if (tr->sealed_ev) (void)hipEventDestroy(tr->sealed_ev);
   dev_free(tr->ctx, tr->fr_d);
   dev_free(tr->ctx, tr->g1_d);

@@ -45,6 +45,7 @@ struct zk_ctx {
   uint32_t msm_window = 0;
   bool flag_q16 = true;     // keep an int16 copy of quantised weights for the prover's contractions of W
   bool relu_packed = true;  // ReLU aux proofs from packed bits (relu_packed.hip) instead of one-Fr-per-bit tensors
+  bool pipeline_fr = true;     // sealed proofs: do not join the Fr groups on the main stream (next proof's groups run right behind)
   bool derive_rounds = false;  // me_open: T_1 .. T_{k-1} from the folding relation behind the MSM batch instead of as MSMs (msm.hip);
                                // off by default: -31 % msm_accum but a 13 ms scalar-multiplication tail, 2 % net
   bool relu_bytes = true;   // ... through byte histograms (rounds 0-4 / 0-3 without a table) rather than the three-round table form

@@ -84,6 +84,7 @@ struct Recorder {
   uint8_t* blob_dev = nullptr;
   size_t blob_cap = 0;
   std::vector<void*> deferred_free;
+  std::vector<void*> held_free;            // temporaries of an UNJOINED execution: released when the owner knows the lanes are done
   bool empty() const { return chains.empty(); }
 };
 static constexpr size_t REC_BLOB_CAP = 4u << 20;
@@ -95,7 +96,8 @@ int rec_begin_chain(zk_ctx* ctx, Recorder* r, uint32_t group = 0);  // sets ctx-
 void rec_split(zk_ctx* ctx, uint32_t group);              // recording: what follows is independent of what came before
 void rec_end_chain(zk_ctx* ctx);                           // clears ctx->rec
 void rec_rollback(zk_ctx* ctx, Recorder* r, size_t keep_chains);  // a recording prove call failed: drop its chains
-int rec_execute(zk_ctx* ctx, Recorder* r);                 // zip + launch on ctx->stream, release temporaries
+int rec_execute(zk_ctx* ctx, Recorder* r, bool join = true);  // zip + launch on ctx->stream; join: home waits for the groups, temporaries released
+void rec_release_held(zk_ctx* ctx, Recorder* r);           // after an unjoined execution, once every group stream is known to be ordered before the caller
 void* rec_blob_put(zk_ctx* ctx, const void* src, size_t bytes);  // -> DEVICE address inside the blob
 int rec_opaque(zk_ctx* ctx, const char* name, uint64_t bytes, std::function<int(hipStream_t)> fn);
 

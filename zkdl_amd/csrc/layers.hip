@@ -258,6 +258,7 @@ void zk_transcript::unseal() {
   (void)hipStreamWaitEvent(ctx->main_stream, sealed_ev, 0);
   sealed = false;
   deferred_keep.clear();  // owned by worker-lane pools; lanes fork from the main stream, i.e. behind this wait
+  rec_release_held(ctx, &rec);  // temporaries of an unjoined Fr phase: the sealed G1 phase waited for every group stream
 }
 
 int zk_transcript::flush() {
@@ -282,10 +283,10 @@ int zk_transcript::seal(uint64_t* out8_d) {
     return out8_d ? transcript_digest_dev(ctx, fr_d, n_fr, g1_d, n_g1, nullptr, out8_d) : ZK_OK;
   }
   unseal();
-  // Fr phase on the main stream + group lanes, joined on the main stream; the G1 stream waits for it below.
-  // (Leaving the lanes unjoined, so that the next proof's groups queue behind them lane by lane, measured
-  // slower: 7.5 vs 7.05 ms/proof -- more LDS-heavy kernels of two proofs end up sharing the chip.)
-  ZK_TRY(rec_execute(ctx, &rec));
+  // Fr phase on the main stream + group lanes; the G1 stream waits for it below.  With "pipeline_fr" the groups are NOT joined on
+  // the main stream: the next proof's groups queue behind this proof's, stream by stream, so a short group no longer idles until
+  // the longest one is done (the temporaries then stay with the recorder until unseal()).
+  ZK_TRY(rec_execute(ctx, &rec, /*join=*/!ctx->pipeline_fr));
   zk_ctx::Lane& g = ctx->g1_lanes[ctx->next_g1++ % ctx->g1_lanes.size()];
   sealed_stream = g.stream;
   if (!sealed_ev && hipEventCreateWithFlags(&sealed_ev, hipEventDisableTiming) != hipSuccess) return ctx->fail(ZK_ERR_DEVICE, "hipEventCreate failed");

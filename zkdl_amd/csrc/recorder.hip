@@ -79,7 +79,7 @@ struct Batch {
 inline bool same_key(const RecOp& a, const RecOp& b) { return a.k && b.k == a.k && b.gy == a.gy && b.shmem == a.shmem; }
 }  // namespace
 
-int rec_execute(zk_ctx* ctx, Recorder* r) {
+int rec_execute(zk_ctx* ctx, Recorder* r, bool join) {
   if (r->chains.empty()) return ZK_OK;
   Recorder* outer = ctx->rec;
   ctx->rec = nullptr;  // launches below are real
@@ -188,21 +188,34 @@ int rec_execute(zk_ctx* ctx, Recorder* r) {
     if (lr != 0) rc = ctx->fail(ZK_ERR_DEVICE, std::string("launch of ") + b.first->name + " failed: " + hipGetErrorString(hipGetLastError()));
   }
   ctx->stream = home;
-  for (zk_ctx::Lane* l : used) {  // join: everything after this on the home stream sees the groups' results
+  for (zk_ctx::Lane* l : used) {
     (void)hipEventRecord(l->done, l->stream);
-    (void)hipStreamWaitEvent(home, l->done, 0);
+    if (join) (void)hipStreamWaitEvent(home, l->done, 0);  // everything after this on the home stream sees the groups' results
+    else l->dirty = true;                                   // unjoined: whoever needs the results waits on the lanes' events
   }
 
-  // ---- temporaries of the recorded calls: stream-ordered release behind the launches above
-  ctx->pool_release(r->blob_dev);
+  // ---- temporaries of the recorded calls.  Joined: stream-ordered release behind the launches above.  Unjoined: the next proof's
+  // groups run right behind this one's, stream by stream, so a block freed here could be handed to ANOTHER group's stream while this
+  // proof still reads it: the blocks (and the blob) stay with the recorder until rec_release_held().
+  if (join) {
+    ctx->pool_release(r->blob_dev);
+    for (void* p : r->deferred_free) ctx->pool_release(p);
+  } else {
+    r->held_free.push_back(r->blob_dev);
+    for (void* p : r->deferred_free) r->held_free.push_back(p);
+  }
   r->blob_dev = nullptr;
-  for (void* p : r->deferred_free) ctx->pool_release(p);
   r->deferred_free.clear();
   r->chains.clear();
   r->args.clear();
   r->blob.clear();
   ctx->rec = outer;
   return rc;
+}
+
+void rec_release_held(zk_ctx* ctx, Recorder* r) {
+  for (void* p : r->held_free) ctx->pool_release(p);
+  r->held_free.clear();
 }
 
 }  // namespace zk
