@@ -597,7 +597,10 @@ static int relu_prove_body(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const 
     ZK_TRY(fr_partial_me_dev(ctx, relu->rem_bin, n * 16, c + offs[4], k, 16, out));
     out += 16;
   }
-  rec_split(ctx, REC_GROUP_FC_OPEN);
+  {
+    static const int hp_group = [] { const char* e = getenv("ZKDL_HP_GROUP"); return e ? atoi(e) : (int)REC_GROUP_FC_OPEN; }();  // A/B: which stream the Hadamard chains share
+    rec_split(ctx, (uint32_t)hp_group);
+  }
   ZK_TRY(sumcheck_hp_dev(ctx, x, relu->sign, n, c + offs[5], c + offs[6], k, out));
   return ZK_OK;
 }
