@@ -545,8 +545,8 @@ def main():
     # MSM items of one proof: the launch is sized for n * W slots per job (its `bytes`), but T0_r / T1_r only touch every other
     # generator (their other scalars are zero and are dropped by the sort): per layer 2 k_lo n + n (T, T0, T1 of every round, the
     # final generator) + m (com(u_hi)) nonzero full-width scalars, 26 ten-bit windows each
-    # (with derived round commitments the k - 1 full-size T_r MSMs are gone: (k + 2) n + m)
-    real_pairs = sum(((ceil_log2(s_["n_gens"]) + 2) if derive else (2 * ceil_log2(s_["n_gens"]) + 1)) * s_["n_gens"] + s_["m"] for s_ in wl.shapes)
+    # (with derived round commitments all k full-size T_r MSMs are gone: (k + 1) n + m)
+    real_pairs = sum(((ceil_log2(s_["n_gens"]) + 1) if derive else (2 * ceil_log2(s_["n_gens"]) + 1)) * s_["n_gens"] + s_["m"] for s_ in wl.shapes)
     if "msm_accum" in prof:
         slots = prof["msm_accum"]["bytes"] / 100.0 / max(prof["msm_accum"]["launches"], 1)
         items = min(slots, real_pairs * 26.0) if args.msm == "pippenger" and not args.msm_window else slots

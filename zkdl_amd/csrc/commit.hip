@@ -15,7 +15,7 @@
 namespace zk {
 
 int commit_pippenger_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, uint32_t tn, G1J* out);
-int me_open_flat_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d, MsmQueue* queue);
+int me_open_flat_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d, MsmQueue* queue, const G1J* com_eval_d);
 int g1_me_msm_dev(zk_ctx* ctx, zk_gens* pts, const Fr* u_d, uint32_t k, G1J* dst_d, MsmQueue* queue);
 
 int gens_create(zk_ctx* ctx, const G1J* gens_d, uint32_t n, bool copy, zk_gens** out) {
@@ -116,13 +116,13 @@ static int me_open_literal_dev(zk_ctx* ctx, const Fr* t, const G1J* gens, uint32
 }
 
 // Commitment::me_open, commitment.cu:62-81
-int me_open_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d, MsmQueue* queue) {
+int me_open_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d, MsmQueue* queue, const G1J* com_eval_d) {
   const uint32_t n = g->n;
   if (n == 0 || k > 31) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   if ((n >> k) == 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");  // a round would see an empty tensor
   // the flattened form needs the full binary tree the prover always has (n == 2^k, commitment.cu:89);
   // ragged sizes, which only the bare me_open API can produce, keep the reference's op sequence
-  if (ctx->msm_mode == ZK_MSM_PIPPENGER && k <= 19 && n == (1u << k)) return me_open_flat_dev(ctx, g, t, u_d, k, proof_d, ret_d, queue);
+  if (ctx->msm_mode == ZK_MSM_PIPPENGER && k <= 19 && n == (1u << k)) return me_open_flat_dev(ctx, g, t, u_d, k, proof_d, ret_d, queue, com_eval_d);
   return me_open_literal_dev(ctx, t, g->pts, n, u_d, k, proof_d, ret_d);
 }
 
@@ -145,7 +145,8 @@ int open_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, uint32_t tn, zk_gens* com, co
   ZK_ALLOC(ctx, folded, Fr, n);
   if (tq && k_hi > 0) ZK_TRY(fr_partial_me_q16_dev(ctx, tq, tn, u_hi, k_hi, n, folded.get()));
   else ZK_TRY(fr_partial_me_dev(ctx, t, tn, u_hi, k_hi, n, folded.get()));
-  return me_open_dev(ctx, g, folded.get(), u_lo, k_lo, proof_d, ret_d, queue);
+  // com_eval_d (this call's com(u_hi), a slot of the same deferred batch) lets the derived-rounds form obtain T_0 = [R] com(u_hi) as well
+  return me_open_dev(ctx, g, folded.get(), u_lo, k_lo, proof_d, ret_d, queue, ctx->msm_mode == ZK_MSM_PIPPENGER ? com_eval_d : nullptr);
 }
 
 }  // namespace zk

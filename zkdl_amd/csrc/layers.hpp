@@ -19,8 +19,9 @@ struct MsmJobHost {  // one pending MSM: *out = sum_j mags[j] * base_j over tabl
 };
 struct DeriveJobHost {  // T_1 .. T_{k-1} of one me_open, derived from T_0 and the T0_j / T1_j behind the MSM batch (msm.hip)
   G1J* proof;            // the me_open's 3k+1 transcript slots
-  const Fr* coef;        // k^2 - 1 raw scalars (k_mo_derive_coef)
+  const Fr* coef;        // k^2 raw scalars (k_mo_derive_coef)
   uint32_t k;
+  const G1J* base;       // com(u_hi) when T_0 is derived too (Commitment::open), else nullptr (T_0 is an MSM)
 };
 struct MsmQueue {  // MSMs enqueued by the provers, executed together by msm_flush()
   std::vector<MsmJobHost> jobs;
@@ -100,7 +101,7 @@ int msm_run_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs, uint32_t c);
 int g1_canonicalise_dev(zk_ctx* ctx, G1J* pts, uint32_t n);
 int commit_dev(zk_ctx* ctx, zk_gens* gens, const Fr* t, uint32_t tn, G1J* out);
 // queue == nullptr: run now; otherwise (PIPPENGER back end) the MSMs are deferred to msm_flush(queue)
-int me_open_dev(zk_ctx* ctx, zk_gens* gens, const Fr* t, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d, MsmQueue* queue);
+int me_open_dev(zk_ctx* ctx, zk_gens* gens, const Fr* t, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d, MsmQueue* queue, const G1J* com_eval_d = nullptr);
 int open_dev(zk_ctx* ctx, zk_gens* gens, const Fr* t, uint32_t tn, zk_gens* com, const Fr* u_d, uint32_t k, G1J* com_eval_d, G1J* proof_d, Fr* ret_d, MsmQueue* queue,
              const int16_t* tq = nullptr);  // tq: optional int16 copy of t (quantised weights)
 int fc_create(zk_ctx* ctx, uint32_t in, uint32_t out, const Fr* weights_d, zk_gens* gens, zk_fc** out_fc);

@@ -666,13 +666,14 @@ __device__ __forceinline__ void k_mo_coef(uint32_t zk_nblk, const Fr* __restrict
 }
 // scal[(3r + e)*n + i] for rounds r < k, e in {T, T0, T1}; scal[3k*n + i] = unmont(C_k[i]).
 // S holds the folded scalar tensors back to back: S_r at offset 2n - (2n >> r).
-// compact != 0 (derived rounds): rows are [T_0][T0_0, T1_0][T0_1, T1_1] .. [final]: T_r, r >= 1, is not an MSM
+// compact = 1 (derived rounds): rows are [T_0][T0_0, T1_0][T0_1, T1_1] .. [final]: T_r, r >= 1, is not an MSM;
+// compact = 2: T_0 is derived as well (from com(u_hi)): rows [T0_0, T1_0] .. [final]
 __device__ __forceinline__ void k_mo_scalars(uint32_t zk_nblk, const Fr* __restrict__ C, const Fr* __restrict__ S, uint32_t n, uint32_t k, Fr* __restrict__ scal, uint32_t compact) {
   uint64_t total = (uint64_t)(k + 1) * n;
   for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)zk_nblk * blockDim.x) {
     uint32_t r = (uint32_t)(g / n), i = (uint32_t)(g - (uint64_t)r * n);
     if (r == k) {
-      scal[(uint64_t)(compact ? 2 * k + 1 : 3 * k) * n + i] = fr_unmont(C[(1u << k) - 1u + i]);
+      scal[(uint64_t)(compact == 2 ? 2 * k : compact ? 2 * k + 1 : 3 * k) * n + i] = fr_unmont(C[(1u << k) - 1u + i]);
       continue;
     }
     uint32_t j = i >> r, l = i & ((1u << r) - 1u);
@@ -680,8 +681,8 @@ __device__ __forceinline__ void k_mo_scalars(uint32_t zk_nblk, const Fr* __restr
     const Fr* Sr = S + (2ull * n - ((2ull * n) >> r));
     Fr zero = fr_zero();
     // mont_mul(C~, s^) = C * s^ mod r as an integer: the MSM scalar of original generator i
-    if (!compact || r == 0) scal[(uint64_t)(3 * r + 0) * n + i] = fr_mul(cf, Sr[j]);
-    const uint32_t r0 = compact ? 2 * r + 1 : 3 * r + 1;
+    if (!compact || (r == 0 && compact == 1)) scal[(uint64_t)(3 * r + 0) * n + i] = fr_mul(cf, Sr[j]);
+    const uint32_t r0 = compact == 2 ? 2 * r : compact ? 2 * r + 1 : 3 * r + 1;
     scal[(uint64_t)r0 * n + i] = (j & 1u) ? fr_mul(cf, Sr[j - 1]) : zero;        // T0 = sum g_{2j+1} * s_{2j}
     scal[(uint64_t)(r0 + 1) * n + i] = (j & 1u) ? zero : fr_mul(cf, Sr[j + 1]);  // T1 = sum g_{2j} * s_{2j+1}
   }
@@ -695,13 +696,16 @@ __device__ __forceinline__ void k_mo_scalars(uint32_t zk_nblk, const Fr* __restr
 // as MSMs (2k + 2 of the 3k + 1: the T_r are the FULL-size ones, 42 % of all (point, window) items of a proof), and T_1 .. T_{k-1}
 // are k^2 - 1 scalar multiplications behind the batch: about 4 ms of latency on a handful of waves, i.e. a longer G1 phase under the
 // following proofs' Fr phases, for a fifth less vector work per proof.  Same group elements as the reference's T_r.
-// coef[r^2 - 1 + s], 1 <= r < k: s = 0 -> T_0; s = 1 + 2j -> T0_j; s = 2 + 2j -> T1_j (j < r); raw integers
-__device__ __forceinline__ void k_mo_derive_coef(uint32_t zk_nblk, const Fr* __restrict__ u, uint32_t k, Fr* __restrict__ coef) {
-  const uint32_t total = k * k - 1;
-  for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += zk_nblk * blockDim.x) {
-    uint32_t r = 1;
-    while ((r + 1) * (r + 1) - 1 <= idx) r++;
-    const uint32_t s = idx - (r * r - 1);
+// coef[r^2 + s], r0 <= r < k: s = 0 -> the base point; s = 1 + 2j -> T0_j; s = 2 + 2j -> T1_j (j < r); raw integers.
+// Base point: T_0 (r0 = 1), or -- inside Commitment::open, where com(u_hi) is known -- com(u_hi) itself (r0 = 0): T_0 = [R] com(u_hi)
+// (the opening multiplies by the Montgomery limbs of scalars whose VALUES commit to com(u_hi); zk_verify_fc checks the same), so the
+// base coefficient is (prod a_i) * R mod r, which is the Montgomery form of the product as it stands, and T_0 is one more derived point.
+__device__ __forceinline__ void k_mo_derive_coef(uint32_t zk_nblk, const Fr* __restrict__ u, uint32_t k, uint32_t r0, Fr* __restrict__ coef) {
+  const uint32_t total = k * k;
+  for (uint32_t idx = r0 + blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += zk_nblk * blockDim.x) {
+    uint32_t r = 0;
+    while ((r + 1) * (r + 1) <= idx) r++;
+    const uint32_t s = idx - r * r;
     const Fr one = fr_one();
     Fr acc = one;
     uint32_t from = 0;  // product of a_i over from <= i < r
@@ -715,13 +719,14 @@ __device__ __forceinline__ void k_mo_derive_coef(uint32_t zk_nblk, const Fr* __r
       const Fr ui = u[i];
       acc = fr_mul(acc, fr_mul(ui, fr_sub(one, ui)));
     }
-    coef[idx] = fr_unmont(acc);
+    coef[idx] = (s == 0 && r0 == 0) ? acc : fr_unmont(acc);
   }
 }
 struct DeriveJob {
   G1J* proof;
+  const G1J* base;   // the point the s = 0 coefficients multiply: proof[0] (T_0) or com(u_hi)
   const Fr* coef;
-  uint32_t k, lane_off;
+  uint32_t k, r0, lane_off;
 };
 // scalar * point with a signed 4-bit fixed window: k + sum_i 8 * 16^i has the nibbles (d_i + 8) with d_i in [-8, 7] and
 // k = sum_i d_i 16^i (no carries between digits: the same recoding as the bucket MSM's), so the lane keeps P .. 8P in a private
@@ -771,12 +776,12 @@ __global__ void __launch_bounds__(64) k_derive_mul(const DeriveJob* __restrict__
   uint32_t q = 0;
   while (q + 1 < nj && jobs[q + 1].lane_off <= lane) q++;
   const DeriveJob job = jobs[q];
-  const uint32_t idx = lane - job.lane_off;
-  uint32_t r = 1;
-  while ((r + 1) * (r + 1) - 1 <= idx) r++;
-  const uint32_t s = idx - (r * r - 1);
-  const uint32_t src = s == 0 ? 0u : 3u * ((s - 1) >> 1) + ((s & 1u) ? 1u : 2u);
-  tmp[lane] = g1_mul_w4(job.proof[src], job.coef[idx], tabs + (size_t)lane * 8);
+  const uint32_t idx = lane - job.lane_off + job.r0;
+  uint32_t r = 0;
+  while ((r + 1) * (r + 1) <= idx) r++;
+  const uint32_t s = idx - r * r;
+  const G1J P = s == 0 ? *job.base : job.proof[3u * ((s - 1) >> 1) + ((s & 1u) ? 1u : 2u)];
+  tmp[lane] = g1_mul_w4(P, job.coef[idx], tabs + (size_t)lane * 8);
 }
 // one lane per (job, r): proof[3r] = sum of its 2r + 1 products
 __global__ void __launch_bounds__(64) k_derive_sum(const DeriveJob* __restrict__ jobs, uint32_t nj, uint32_t nseg, const uint32_t* __restrict__ seg_job, const G1J* __restrict__ tmp) {
@@ -784,7 +789,7 @@ __global__ void __launch_bounds__(64) k_derive_sum(const DeriveJob* __restrict__
   if (t >= nseg) return;
   const uint32_t q = seg_job[2 * t], r = seg_job[2 * t + 1];
   const DeriveJob job = jobs[q];
-  const G1J* p = tmp + job.lane_off + (r * r - 1);
+  const G1J* p = tmp + job.lane_off + (r * r - job.r0);
   G1J acc = p[0];
   for (uint32_t s = 1; s < 2 * r + 1; s++) acc = g1_add(acc, p[s]);
   job.proof[3 * r] = acc;
@@ -797,13 +802,14 @@ int msm_run_derives(zk_ctx* ctx, const std::vector<DeriveJobHost>& derives) {
   std::vector<uint32_t> seg;
   uint32_t total = 0;
   for (const auto& d : derives) {
-    if (d.k < 2) continue;
-    for (uint32_t r = 1; r < d.k; r++) {
+    const uint32_t r0 = d.base ? 0u : 1u;
+    if (d.k <= r0) continue;
+    for (uint32_t r = r0; r < d.k; r++) {
       seg.push_back((uint32_t)jobs.size());
       seg.push_back(r);
     }
-    jobs.push_back(DeriveJob{d.proof, d.coef, d.k, total});
-    total += d.k * d.k - 1;
+    jobs.push_back(DeriveJob{d.proof, d.base ? d.base : d.proof, d.coef, d.k, r0, total});
+    total += d.k * d.k - r0;
   }
   if (jobs.empty()) return ZK_OK;
   const uint32_t nj = (uint32_t)jobs.size(), nseg = (uint32_t)seg.size() / 2;
@@ -824,7 +830,7 @@ int msm_run_derives(zk_ctx* ctx, const std::vector<DeriveJobHost>& derives) {
   return ZK_OK;
 }
 
-int me_open_flat_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d, MsmQueue* queue) {
+int me_open_flat_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d, MsmQueue* queue, const G1J* com_eval_d) {
   const uint32_t n = g->n;
   if (k > 19 || n != (1u << k)) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions (flattened me_open needs n == 2^k)");
   // folded scalar tensors S_0 .. S_k (Fr only, tiny)
@@ -839,15 +845,16 @@ int me_open_flat_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32
   uint32_t ncoef = (2u << k) - 1u;
   ZK_ALLOC(ctx, C, Fr, ncoef);
   ZK_LAUNCHB(ctx, "me_open_scalars", 32ull * ncoef, 256, k_mo_coef, dim3((ncoef + 255) / 256), 0, u_d, k, C.get());
-  const bool derive = queue && ctx->derive_rounds && k >= 2;
-  uint32_t q = derive ? 2 * k + 2 : 3 * k + 1;
+  const bool derive = queue && ctx->derive_rounds && (k >= 2 || (com_eval_d && k >= 1));
+  const bool from_com = derive && com_eval_d != nullptr;  // T_0 too: [R] com(u_hi)
+  uint32_t q = from_com ? 2 * k + 1 : derive ? 2 * k + 2 : 3 * k + 1;
   ZK_ALLOC(ctx, scal, Fr, (size_t)q * n);
   ZK_LAUNCHB(ctx, "me_open_scalars", 32ull * q * n, 256, k_mo_scalars, dim3(stream_grid((uint64_t)(k + 1) * n)), 0, (const Fr*)C.get(), (const Fr*)S.get(), n, k,
-            scal.get(), derive ? 1u : 0u);
+            scal.get(), from_com ? 2u : derive ? 1u : 0u);
   if (derive) {
-    // deferred batch: T_0, every T0_r / T1_r and the final generator as MSMs; T_1 .. T_{k-1} derived behind the batch
+    // deferred batch: [T_0,] every T0_r / T1_r and the final generator as MSMs; the T_r derived behind the batch
     std::vector<uint32_t> rows;
-    rows.push_back(0);
+    if (!from_com) rows.push_back(0);
     for (uint32_t r = 0; r < k; r++) {
       rows.push_back(3 * r + 1);
       rows.push_back(3 * r + 2);
@@ -856,8 +863,8 @@ int me_open_flat_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32
     ZK_TRY(msm_enqueue(ctx, g, scal.get(), q, /*do_unmont=*/false, /*probe_bits=*/false, proof_d, queue, rows.data()));
     DBuf<Fr> coef;
     if (!coef.alloc(ctx, (size_t)k * k)) return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: derive coefficients");
-    ZK_LAUNCHB(ctx, "me_open_scalars", 32ull * k * k, 64, k_mo_derive_coef, dim3((k * k + 63) / 64), 0, u_d, k, coef.get());
-    queue->derives.push_back(DeriveJobHost{proof_d, coef.get(), k});
+    ZK_LAUNCHB(ctx, "me_open_scalars", 32ull * k * k, 64, k_mo_derive_coef, dim3((k * k + 63) / 64), 0, u_d, k, from_com ? 0u : 1u, coef.get());
+    queue->derives.push_back(DeriveJobHost{proof_d, coef.get(), k, from_com ? com_eval_d : nullptr});
     queue->keep.push_back(std::move(coef));
     return ZK_OK;
   }
