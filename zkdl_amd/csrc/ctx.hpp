@@ -403,7 +403,7 @@ int fr_random_int_dev(zk_ctx* ctx, Fr* out, uint32_t n, uint32_t num_bits);
 enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_NEG = 3, OP_MONT = 4, OP_UNMONT = 5 };
 // sumcheck.hip
 int sumcheck_ip_dev(zk_ctx* ctx, const Fr* a, const Fr* b, uint32_t n, const Fr* u_d, uint32_t k, Fr* proof_d);
-int sumcheck_hp_dev(zk_ctx* ctx, const Fr* a, const Fr* b, uint32_t n, const Fr* u_d, const Fr* v_d, uint32_t k, Fr* proof_d);
+int sumcheck_hp_dev(zk_ctx* ctx, const Fr* a, const Fr* b, uint32_t n, const Fr* u_d, const Fr* v_d, uint32_t k, Fr* proof_d, const uint8_t* b_bits = nullptr);
 int sumcheck_bin_dev(zk_ctx* ctx, const Fr* a, uint32_t n, const Fr* u_d, const Fr* v_d, uint32_t k, Fr* proof_d);
 // g1_kernels.hip
 int g1_sum_dev(zk_ctx* ctx, const G1J* a, uint32_t n, G1J* dst_d);

@@ -601,7 +601,7 @@ static int relu_prove_body(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const 
     static const int hp_group = [] { const char* e = getenv("ZKDL_HP_GROUP"); return e ? atoi(e) : (int)REC_GROUP_FC_OPEN; }();  // A/B: which stream the Hadamard chains share
     rec_split(ctx, (uint32_t)hp_group);
   }
-  ZK_TRY(sumcheck_hp_dev(ctx, x, relu->sign, n, c + offs[5], c + offs[6], k, out));
+  ZK_TRY(sumcheck_hp_dev(ctx, x, relu->sign, n, c + offs[5], c + offs[6], k, out, ctx->relu_packed ? relu->sign_packed : nullptr));
   return ZK_OK;
 }
 

@@ -187,6 +187,59 @@ __device__ __forceinline__ void k_sc_round(uint32_t zk_nblk, const Fr* __restric
   }
 }
 
+// Round 0 of a Hadamard sumcheck whose second operand is a 0/1 tensor given as one BYTE per element (zkReLU's sign tensor:
+// sign_packed): with b in {0, 1} four of the round's seven products are selects --
+//     c0 = b0 ? a0 w : 0,   (a0 w + da w) b1 = b1 ? a1 w : 0,   c2 = da w (b1 - b0) = 0 or +-da w,   b' = b0 + x (b1 - b0) in {0, x, 1 - x, 1}
+// -- and the operand is read as 1 byte instead of 32.  Same coefficients, same folded tables (now as field elements) as k_sc_round<SC_HP, 1>.
+__device__ __forceinline__ void k_sc_round_hp0(uint32_t zk_nblk, const Fr* __restrict__ a, const uint8_t* __restrict__ bb, Fr* __restrict__ a_out, Fr* __restrict__ b_out,
+                                                       const Fr* __restrict__ fold, ScLevels lv, const Fr* __restrict__ B, uint32_t in_size, uint32_t out_size,
+                                                       Fr* __restrict__ partial) {
+  __shared__ Fr lds[12];
+  const Fr x = fold[0], one = fr_one(), zero = fr_zero();
+  const Fr nx = fr_sub(one, x);
+  Fr acc0 = zero, acc1 = zero, acc2 = zero;
+  const uint32_t P = out_size / zk_nblk;
+  const bool fact = lv.c[2] != 0xffu && P * zk_nblk == out_size && P >= blockDim.x && P % blockDim.x == 0 && lv.c[0] < 32 && P <= (1u << lv.c[0]) && ((1u << lv.c[0]) % P) == 0;
+  const uint32_t mask = (1u << lv.c[0]) - 1u;
+  auto sweep = [&](auto FACT) {
+    const uint32_t g_first = FACT.value ? blockIdx.x * P + threadIdx.x : blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t g_end = FACT.value ? (blockIdx.x + 1) * P : out_size;
+    const uint32_t g_step = FACT.value ? blockDim.x : zk_nblk * blockDim.x;
+    for (uint32_t g = g_first; g < g_end; g += g_step) {
+      const uint64_t e0 = 2ull * g, e1 = e0 + 1;
+      const Fr a0 = e0 < in_size ? a[e0] : zero, a1 = e1 < in_size ? a[e1] : zero;
+      const bool b0 = e0 < in_size && bb[e0] != 0, b1 = e1 < in_size && bb[e1] != 0;
+      Fr w = lv.A[0][g & mask];
+      if constexpr (!decltype(FACT)::value) w = fr_mul(w, B[g >> lv.c[0]]);
+      const Fr da = fr_sub(a1, a0);
+      const Fr a0w = fr_mul(a0, w), daw = fr_mul(da, w);
+      const Fr c0 = b0 ? a0w : zero;
+      const Fr t = b1 ? fr_add(a0w, daw) : zero;
+      const Fr c2 = b0 == b1 ? zero : (b1 ? daw : fr_neg(daw));
+      acc0 = fr_add(acc0, c0);
+      acc1 = fr_add(acc1, fr_sub(fr_sub(t, c0), c2));
+      acc2 = fr_add(acc2, c2);
+      a_out[g] = fr_add(a0, fr_mul(x, da));
+      b_out[g] = b0 ? (b1 ? one : nx) : (b1 ? x : zero);
+    }
+  };
+  if (fact) sweep(std::true_type{});
+  else sweep(std::false_type{});
+  block_sum3_fr(acc0, acc1, acc2, lds);
+  if (threadIdx.x == 0) {
+    Fr t0 = acc0, t1 = acc1, t2 = acc2;
+    if (fact) {
+      const Fr bw = B[(blockIdx.x * P) >> lv.c[0]];
+      t0 = fr_mul(t0, bw);
+      t1 = fr_mul(t1, bw);
+      t2 = fr_mul(t2, bw);
+    }
+    partial[(uint64_t)blockIdx.x * 3 + 0] = t0;
+    partial[(uint64_t)blockIdx.x * 3 + 1] = t1;
+    partial[(uint64_t)blockIdx.x * 3 + 2] = t2;
+  }
+}
+
 // All remaining rounds with the table(s) resident in LDS.  n <= SC_TAIL_N, rounds r0 .. k-1.
 // fold = fold challenges (all k), w = weight challenges (all k) or nullptr for SC_IP.
 // Also closes the last big round (prev_*), and writes the final a(0) [, b(0)].
@@ -281,7 +334,7 @@ __device__ __forceinline__ void k_sc_tail(uint32_t zk_nblk, const Fr* __restrict
 }
 
 template <int MODE>
-static int run_sumcheck(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n, const Fr* fold_d, const Fr* weight_d, uint32_t k, Fr* proof_d) {
+static int run_sumcheck(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n, const Fr* fold_d, const Fr* weight_d, uint32_t k, Fr* proof_d, const uint8_t* b_bits = nullptr) {
   const bool two = (MODE != SC_BIN);
   // big rounds: while the live table is longer than SC_TAIL_N
   uint32_t nbig = 0;
@@ -345,6 +398,20 @@ static int run_sumcheck(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n,
     Fr* bo = b_slots[launch & 1];
     Fr* part = partial.get() + (launch & 1) * 9 * SC_MAX_BLOCKS;
     uint64_t bytes = (two ? 2ull : 1ull) * 32ull * ((uint64_t)sz + osz);
+    static const bool no_hp0 = getenv("ZKDL_NO_HP0") != nullptr;  // A/B switch
+    if (MODE == SC_HP && b_bits && r == 0 && !no_hp0) {  // 0/1 second operand, one byte per element: round 0 without its products by b
+      ZK_LAUNCHB(ctx, tag, 32ull * ((uint64_t)sz + 2ull * osz) + sz, 256, k_sc_round_hp0, dim3(grid), 0, a, b_bits, ao, bo, fold_d, lv, (const Fr*)tabB.get(), sz, osz, part);
+      prev_partial = part;
+      prev_blocks = grid;
+      prev_cols = 3;
+      prev_dst = proof_d;
+      a = ao;
+      b = bo;
+      sz = osz;
+      r += 1;
+      launch++;
+      continue;
+    }
 #define ZK_SC_LAUNCH(RR)                                                                                                                                   \
   ZK_LAUNCHB(ctx, tag, bytes, 256, (k_sc_round<MODE, RR>), dim3(grid), 0, a, b, ao, bo, fold_d + r, lv, (const Fr*)tabB.get(), sz, osz, part, prev_partial, \
             prev_blocks, prev_cols, prev_dst)
@@ -378,10 +445,11 @@ int sumcheck_ip_dev(zk_ctx* ctx, const Fr* a, const Fr* b, uint32_t n, const Fr*
   return run_sumcheck<SC_IP>(ctx, a, b, n, u_d, nullptr, k, proof_d);
 }
 // hadamard_product_sumcheck guards: proof.cu:139-150
-int sumcheck_hp_dev(zk_ctx* ctx, const Fr* a, const Fr* b, uint32_t n, const Fr* u_d, const Fr* v_d, uint32_t k, Fr* proof_d) {
+// b_bits (optional): b as one byte per element, for a 0/1-valued b (the values of b[] must then be 0 or the Montgomery one)
+int sumcheck_hp_dev(zk_ctx* ctx, const Fr* a, const Fr* b, uint32_t n, const Fr* u_d, const Fr* v_d, uint32_t k, Fr* proof_d, const uint8_t* b_bits) {
   if (n == 0 || k > 31 || n > (1u << k)) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions 4");
   if (k > 0 && n <= (1u << (k - 1))) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions 3");
-  return run_sumcheck<SC_HP>(ctx, a, b, n, v_d, u_d, k, proof_d);
+  return run_sumcheck<SC_HP>(ctx, a, b, n, v_d, u_d, k, proof_d, b_bits);
 }
 // binary_sumcheck guards: proof.cu:190-200
 int sumcheck_bin_dev(zk_ctx* ctx, const Fr* a, uint32_t n, const Fr* u_d, const Fr* v_d, uint32_t k, Fr* proof_d) {
