@@ -268,6 +268,12 @@ void* zk_transcript_stream(zk_transcript* tr);
 int zk_verify_fc(zk_ctx* ctx, zk_gens* gens, const zk_g1j* com_d, uint32_t m, uint32_t batch, uint32_t in, uint32_t out, int z_is_raw,
                  const zk_fr* u_bs_h, const zk_fr* u_in_h, const zk_fr* u_out_h, const zk_fr* fr_h, size_t n_fr, const zk_g1a* g1_h, const uint8_t* inf_h,
                  size_t n_g1, const zk_fr* expect_z_h, const zk_fr* expect_x_h, zk_fr* claim_z_h, zk_fr* claim_x_h, int* ok);
+/* zk_verify_open -- one Commitment::open (commitment.cu:83-92) on its own: g1_h = [com(u_hi)][me_open 3 k_lo + 1] as zk_open returns them
+ * (affine-canonical), value_h the opened value t(0) (Montgomery form) = the committed tensor's multilinear evaluation at u (k = k_lo + k_hi
+ * challenges: generator bits first, then commitment rows).  The checks are zk_verify_fc's opening checks; used for ACTIVATION commitments
+ * (the reference's stated future work: commit Z_i / A_i with zk_commit, open them at the points the layer proofs leave as open claims). */
+int zk_verify_open(zk_ctx* ctx, zk_gens* gens, const zk_g1j* com_d, uint32_t m, const zk_fr* u_h, uint32_t k, const zk_fr* value_h,
+                   const zk_g1a* g1_h, const uint8_t* inf_h, size_t n_g1, int* ok);
 /* zk_verify_relu -- one zkReLU::prove (zkrelu.cu:79-100) over n elements: fr_h as zk_relu_prove appends it.  Checks both
  * binary sumchecks (proof.cu:152-188) and the Hadamard sumcheck (proof.cu:110-137).  The reference binds none of the
  * ReLU's final evaluations to a commitment (activation commitments are its stated future work), so they are returned as

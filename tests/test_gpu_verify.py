@@ -129,3 +129,44 @@ def test_verifier_accepts_the_full_size_proof(zk):
     bad = bytearray(blob)
     bad[24 + 32 * 100 + 5] ^= 4
     assert not verify_mlp(zk, dims, batch, wl.gens, coms, wl.X, wl.Yhat, bytes(bad), chal=chal)[0]
+
+
+def test_activation_commitments_close_the_inter_layer_claims(zk, oracle):
+    """The reference's future work, on top of its proof: commit Z_i / A_i, open them at the points the layer proofs leave as open claims,
+    verify the openings against the commitments (zk_verify_open).  Honest: verifies.  An opening against another tensor's commitment, a
+    tampered opening, or a claim that is not the committed tensor's evaluation: rejected."""
+    from zkdl_amd.proof import (activation_claims, claimed_activation_values, commit_activations, open_activations, verify_activation_openings,
+                                verify_mlp)
+    dims, batch = [16, 32, 24, 8], 4
+    model, st, coms, chal, blob = build_and_prove(zk, oracle, dims, batch, seed=33)
+    ok, msg, open_claims = verify_mlp(zk, dims, batch, st["gens"], coms, st["X"], st["Yhat"], blob, chal=chal)
+    assert ok, msg
+    committed = commit_activations(zk, st["gens"], st["Z"], st["A"])
+    claims = activation_claims(dims, batch, chal)
+    assert [n for n, _ in claims] == ["A1", "Z1", "Z1", "A0", "Z0", "Z0"]          # fc2 | relu1, fc1 | relu0, fc0 (call order)
+    openings = open_activations(zk, committed, claims)
+    values = claimed_activation_values(dims, open_claims)
+    public = {k: (g, com) for k, (g, t, com) in committed.items()}
+    ok, msg = verify_activation_openings(zk, public, claims, openings, values)
+    assert ok, msg
+    # the opened values ARE the layer proofs' claims (same numbers from two independent computations: sumcheck transcript vs opening)
+    for (name, val, _, _), want in zip(openings, values):
+        assert np.array_equal(np.asarray(val).reshape(8), np.asarray(want).reshape(8)), name
+    # another tensor's commitment
+    swapped = dict(public)
+    swapped["Z1"], swapped["A1"] = (public["Z1"][0], public["A1"][1]), (public["A1"][0], public["Z1"][1])
+    assert not verify_activation_openings(zk, swapped, claims, openings, values)[0]
+    # a tampered opening point
+    bad = [(n, v, a.copy(), i) for n, v, a, i in openings]
+    bad[2][2][3, 5] ^= 1
+    assert not verify_activation_openings(zk, public, claims, bad, values)[0]
+    # a false claim: the layer proof's value replaced (the opening then opens something else)
+    wrong = [v.copy() for v in values]
+    wrong[4][0] ^= 1
+    assert not verify_activation_openings(zk, public, claims, openings, wrong)[0]
+    # a cheating opening for that false claim: the prover cannot produce one from the committed tensor -- opening a different tensor fails T_0
+    other = zk.fr_add(st["Z"][0], st["Z"][0])
+    ret, com_eval, proof = zk.open(st["gens"][0], other, committed["Z0"][2], claims[4][1])
+    aff, inf = zk.g1_to_affine(zk.upload(np.concatenate([com_eval.reshape(1, 36), proof])))
+    ok, _ = zk.verify_open(st["gens"][0], committed["Z0"][2], claims[4][1], ret, aff, inf)
+    assert not ok

@@ -34,7 +34,7 @@ zk_fc_out zk_fc_com_size zk_fc_weights zk_fc_com zk_fc_load_input zk_fc_forward 
 zk_relu_destroy zk_relu_forward zk_relu_sign zk_relu_mag_bin zk_relu_rem_bin zk_relu_prove zk_transcript_create
 zk_transcript_destroy zk_transcript_reset zk_transcript_flush zk_transcript_counts zk_transcript_read zk_transcript_read_affine
 zk_transcript_digest zk_transcript_digest_dev zk_transcript_serialize zk_transcript_seal zk_transcript_stream
-zk_verify_fc zk_verify_relu zk_fs_derive zk_sha256""".split()
+zk_verify_fc zk_verify_relu zk_verify_open zk_fs_derive zk_sha256""".split()
 
 
 class ZkError(RuntimeError):
@@ -451,6 +451,16 @@ class Zk:
                                         _hp(_fr_host(ch[0])), _hp(_fr_host(ch[1])), _hp(_fr_host(ch[2])), _hp(fr), _sz(fr.shape[0]), _hp(aff), _hp(inf), _sz(aff.shape[0]),
                                         ez, ex, _hp(cz), _hp(cx), ctypes.byref(ok)))
         return bool(ok.value), ("" if ok.value else self.lib.zk_last_error(self.ctx).decode()), cz, cx
+
+    def verify_open(self, gens, com, u, value, aff, inf):
+        """zk_verify_open: an opening of the commitment `com` (DevArray of points) at u with opened value `value`."""
+        u = np.ascontiguousarray(u, dtype=np.uint32).reshape(-1, 8)
+        aff = np.ascontiguousarray(aff, dtype=np.uint32).reshape(-1, 24)
+        inf = np.ascontiguousarray(inf, dtype=np.uint8).reshape(-1)
+        ok = ctypes.c_int(0)
+        self._chk(self.lib.zk_verify_open(self.ctx, gens.h, _vp(com.ptr), _u32(com.n), _hp(_fr_host(u)), _u32(u.shape[0]), _hp(_fr_host(value, 1)), _hp(aff), _hp(inf),
+                                          _sz(aff.shape[0]), ctypes.byref(ok)))
+        return bool(ok.value), ("" if ok.value else self.lib.zk_last_error(self.ctx).decode())
 
     def verify_relu(self, n, ch, fr):
         """zk_verify_relu: ch in zk_relu_prove's order (7 vectors; u_rec is not used by any check).  Returns

@@ -134,6 +134,82 @@ G1J from_affine(const G1A& a, bool inf) {
 }
 }  // namespace
 
+namespace {
+// Commitment::open / me_open (commitment.cu:43-92) against a public commitment: g1 = [com(u_hi)][T, T0, T1 per round][g_final].
+// u: k = k_lo + k_hi challenges, the first k_lo fold the generator index, the last k_hi the commitment rows (commitment.cu:85-86);
+// t0: the opened value (Montgomery form) = the committed tensor's multilinear evaluation at u.
+int verify_opening(zk_ctx* ctx, const Fail& fail, zk_gens* gens, const zk_g1j* com_d, uint32_t m, const zk_fr* u_h, uint32_t k, const Fr& t0, const zk_g1a* g1_h,
+                   const uint8_t* inf_h, bool* passed) {
+  *passed = false;
+  const uint32_t n_gens = gens->n;
+  const uint32_t k_lo = ceil_log2(n_gens), k_hi = ceil_log2(m);
+  // me_open folds the generators the other way round from the scalars, g' = g1 + u (g0 - g1) (commitment.cu:54-56): the final
+  // generator is the multilinear evaluation of the generators at 1 - u
+  std::vector<zk_fr> u(k + k_lo + 1);
+  for (uint32_t i = 0; i < k; i++) u[i] = u_h[i];
+  for (uint32_t i = 0; i < k_lo; i++) {
+    const Fr c = fr_sub(fr_one(), ld(&u[i]));
+    memcpy(&u[k + i], &c, sizeof c);
+  }
+  DBuf<Fr> ud;
+  ZK_TRY(upload_fr(ctx, ud, u.data(), k + k_lo));
+  ZK_ALLOC(ctx, evals, G1J, 2);
+  ZK_TRY(g1_me_dev(ctx, reinterpret_cast<const G1J*>(com_d), m, ud.get() + k_lo, k_hi, evals.get()));          // com(u_hi)
+  ZK_TRY(g1_me_dev(ctx, gens->pts, n_gens, ud.get() + k, k_lo, evals.get() + 1));                               // generators(1 - u_lo)
+  // the 3 k_lo + 2 scalar multiplications of the folding relation, as one batched launch of the literal kernel:
+  //   [R] com_eval | per round: u(1-u) T_r, (1-u)^2 T0_r, u^2 T1_r | t(0) g_final      (scalars = raw integers)
+  const size_t nmul = 3 * (size_t)k_lo + 2;
+  std::vector<G1J> pts(nmul);
+  std::vector<Fr> sc(nmul);
+  auto tp = [&](size_t i) { return from_affine(lda(&g1_h[i]), inf_h[i] != 0); };
+  pts[0] = tp(0);
+  sc[0] = fr_one();  // raw limbs of the Montgomery one = R mod r
+  const Fr one = fr_one();
+  for (uint32_t r = 0; r < k_lo; r++) {
+    const Fr ur = ld(&u[r]), nur = fr_sub(one, ur);
+    pts[1 + 3 * r] = tp(1 + 3 * r);
+    pts[2 + 3 * r] = tp(2 + 3 * r);
+    pts[3 + 3 * r] = tp(3 + 3 * r);
+    sc[1 + 3 * r] = fr_unmont(fr_mul(ur, nur));
+    sc[2 + 3 * r] = fr_unmont(fr_mul(nur, nur));
+    sc[3 + 3 * r] = fr_unmont(fr_mul(ur, ur));
+  }
+  pts[nmul - 1] = tp(3 * (size_t)k_lo + 1);
+  sc[nmul - 1] = t0;  // me_open multiplies by the RAW limbs of the (Montgomery-form) scalars (commitment.cu:57-59)
+  ZK_ALLOC(ctx, pd, G1J, nmul);
+  ZK_ALLOC(ctx, sd, Fr, nmul);
+  ZK_ALLOC(ctx, od, G1J, nmul);
+  ZK_TRY(host_to_dev(ctx, pd.get(), pts.data(), nmul * sizeof(G1J)));
+  ZK_TRY(host_to_dev(ctx, sd.get(), sc.data(), nmul * sizeof(Fr)));
+  ZK_TRY(g1_mul_dev(ctx, pd.get(), (uint32_t)nmul, sd.get(), (uint32_t)nmul, od.get()));
+  std::vector<G1J> prod(nmul);
+  G1J ev[2];
+  ZK_TRY(dev_to_host(ctx, prod.data(), od.get(), nmul * sizeof(G1J)));
+  ZK_TRY(dev_to_host(ctx, ev, evals.get(), sizeof ev));
+  if (!same_point(ev[0], lda(&g1_h[0]), inf_h[0] != 0)) return fail("com(u_hi) is not the multilinear evaluation of the commitment");
+  if (!same_point(ev[1], lda(&g1_h[3 * (size_t)k_lo + 1]), inf_h[3 * (size_t)k_lo + 1] != 0))
+    return fail("the final generator is not the multilinear evaluation of the generators");
+  G1J cur = prod[0];  // commitment of the round's scalars under the round's generators, as it must be
+  for (uint32_t r = 0; r < k_lo; r++) {
+    if (!same_point(cur, lda(&g1_h[1 + 3 * r]), inf_h[1 + 3 * r] != 0))
+      return fail(r == 0 ? std::string("T_0 does not commit to the row-folded tensor") : "me_open round " + std::to_string(r - 1) + ": folding relation violated");
+    cur = g1_add(g1_add(prod[1 + 3 * r], prod[2 + 3 * r]), prod[3 + 3 * r]);
+  }
+  {
+    const G1J want = prod[nmul - 1];  // t(0) * g_final
+    const bool ci = l_is_zero(cur.z), wi = l_is_zero(want.z);
+    bool same = ci && wi;
+    if (!ci && !wi) {
+      const Fp z1 = fp_sqr(cur.z), z2 = fp_sqr(want.z);
+      same = l_eq(fp_mul(cur.x, z2), fp_mul(want.x, z1)) && l_eq(fp_mul(cur.y, fp_mul(z2, want.z)), fp_mul(want.y, fp_mul(z1, cur.z)));
+    }
+    if (!same) return fail(k_lo ? "me_open: last folding relation / final opening t(0) * g_final violated" : "opening of a single generator violated");
+  }
+  *passed = true;
+  return ZK_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int zk_sha256(const void* data, size_t len, uint8_t* out32) {
@@ -203,72 +279,34 @@ int zk_verify_fc(zk_ctx* ctx, zk_gens* gens, const zk_g1j* com_d, uint32_t m, ui
   if (!feq(fb, t0)) return fail("the opening's scalar differs from the sumcheck's W~(u_out || u_in)");
   if (claim_x_h) memcpy(claim_x_h, &fa, sizeof fa);
   if (expect_x_h && !feq(fa, ld(expect_x_h))) return fail("X~(u_in || u_bs) differs from the expected evaluation of the layer's input");
-  // ---- the opening (commitment.cu:43-92).  u = u_out || u_in; the first k_lo entries fold the generator index, the last
-  // k_hi the commitment rows (commitment.cu:85-86)
-  // me_open folds the generators the other way round from the scalars, g' = g1 + u (g0 - g1) (commitment.cu:54-56): the final
-  // generator is the multilinear evaluation of the generators at 1 - u
-  std::vector<zk_fr> u(k_out + k_in + k_lo + 1);
-  for (uint32_t i = 0; i < k_out; i++) u[i] = u_out_h[i];
-  for (uint32_t i = 0; i < k_in; i++) u[k_out + i] = u_in_h[i];
-  for (uint32_t i = 0; i < k_lo; i++) {
-    const Fr c = fr_sub(fr_one(), ld(&u[i]));
-    memcpy(&u[k_out + k_in + i], &c, sizeof c);
-  }
-  DBuf<Fr> ud;
-  ZK_TRY(upload_fr(ctx, ud, u.data(), k_out + k_in + k_lo));
-  ZK_ALLOC(ctx, evals, G1J, 2);
-  ZK_TRY(g1_me_dev(ctx, reinterpret_cast<const G1J*>(com_d), m, ud.get() + k_lo, k_hi, evals.get()));          // com(u_hi)
-  ZK_TRY(g1_me_dev(ctx, gens->pts, n_gens, ud.get() + k_out + k_in, k_lo, evals.get() + 1));                    // generators(1 - u_lo)
-  // the 3 k_lo + 2 scalar multiplications of the folding relation, as one batched launch of the literal kernel:
-  //   [R] com_eval | per round: u(1-u) T_r, (1-u)^2 T0_r, u^2 T1_r | t(0) g_final      (scalars = raw integers)
-  const size_t nmul = 3 * (size_t)k_lo + 2;
-  std::vector<G1J> pts(nmul);
-  std::vector<Fr> sc(nmul);
-  auto tp = [&](size_t i) { return from_affine(lda(&g1_h[i]), inf_h[i] != 0); };
-  pts[0] = tp(0);
-  sc[0] = fr_one();  // raw limbs of the Montgomery one = R mod r
-  const Fr one = fr_one();
-  for (uint32_t r = 0; r < k_lo; r++) {
-    const Fr ur = ld(&u[r]), nur = fr_sub(one, ur);
-    pts[1 + 3 * r] = tp(1 + 3 * r);
-    pts[2 + 3 * r] = tp(2 + 3 * r);
-    pts[3 + 3 * r] = tp(3 + 3 * r);
-    sc[1 + 3 * r] = fr_unmont(fr_mul(ur, nur));
-    sc[2 + 3 * r] = fr_unmont(fr_mul(nur, nur));
-    sc[3 + 3 * r] = fr_unmont(fr_mul(ur, ur));
-  }
-  pts[nmul - 1] = tp(3 * (size_t)k_lo + 1);
-  sc[nmul - 1] = t0;  // me_open multiplies by the RAW limbs of the (Montgomery-form) scalars (commitment.cu:57-59)
-  ZK_ALLOC(ctx, pd, G1J, nmul);
-  ZK_ALLOC(ctx, sd, Fr, nmul);
-  ZK_ALLOC(ctx, od, G1J, nmul);
-  ZK_TRY(host_to_dev(ctx, pd.get(), pts.data(), nmul * sizeof(G1J)));
-  ZK_TRY(host_to_dev(ctx, sd.get(), sc.data(), nmul * sizeof(Fr)));
-  ZK_TRY(g1_mul_dev(ctx, pd.get(), (uint32_t)nmul, sd.get(), (uint32_t)nmul, od.get()));
-  std::vector<G1J> prod(nmul);
-  G1J ev[2];
-  ZK_TRY(dev_to_host(ctx, prod.data(), od.get(), nmul * sizeof(G1J)));
-  ZK_TRY(dev_to_host(ctx, ev, evals.get(), sizeof ev));
-  if (!same_point(ev[0], lda(&g1_h[0]), inf_h[0] != 0)) return fail("com(u_hi) is not the multilinear evaluation of the layer's commitment");
-  if (!same_point(ev[1], lda(&g1_h[3 * (size_t)k_lo + 1]), inf_h[3 * (size_t)k_lo + 1] != 0))
-    return fail("the final generator is not the multilinear evaluation of the generators");
-  G1J cur = prod[0];  // commitment of the round's scalars under the round's generators, as it must be
-  for (uint32_t r = 0; r < k_lo; r++) {
-    if (!same_point(cur, lda(&g1_h[1 + 3 * r]), inf_h[1 + 3 * r] != 0))
-      return fail(r == 0 ? std::string("T_0 does not commit to the row-folded weights") : "me_open round " + std::to_string(r - 1) + ": folding relation violated");
-    cur = g1_add(g1_add(prod[1 + 3 * r], prod[2 + 3 * r]), prod[3 + 3 * r]);
-  }
+  // ---- the opening (commitment.cu:43-92) of W at u = u_out || u_in
   {
-    const G1J want = prod[nmul - 1];  // t(0) * g_final
-    const bool ci = l_is_zero(cur.z), wi = l_is_zero(want.z);
-    bool same = ci && wi;
-    if (!ci && !wi) {
-      const Fp z1 = fp_sqr(cur.z), z2 = fp_sqr(want.z);
-      same = l_eq(fp_mul(cur.x, z2), fp_mul(want.x, z1)) && l_eq(fp_mul(cur.y, fp_mul(z2, want.z)), fp_mul(want.y, fp_mul(z1, cur.z)));
-    }
-    if (!same) return fail(k_lo ? "me_open: last folding relation / final opening t(0) * g_final violated" : "opening of a single generator violated");
+    std::vector<zk_fr> u(k_out + k_in + 1);
+    for (uint32_t i = 0; i < k_out; i++) u[i] = u_out_h[i];
+    for (uint32_t i = 0; i < k_in; i++) u[k_out + i] = u_in_h[i];
+    bool passed = false;
+    ZK_TRY(verify_opening(ctx, fail, gens, com_d, m, u.data(), k_out + k_in, t0, g1_h, inf_h, &passed));
+    if (!passed) return ZK_OK;  // *ok = 0 and the message were set by fail
   }
   *ok = 1;
+  return ZK_OK;
+}
+
+int zk_verify_open(zk_ctx* ctx, zk_gens* gens, const zk_g1j* com_d, uint32_t m, const zk_fr* u_h, uint32_t k, const zk_fr* value_h, const zk_g1a* g1_h,
+                   const uint8_t* inf_h, size_t n_g1, int* ok) {
+  if (!ctx) return ZK_ERR_ARG;
+  {
+    int src = ctx->settle();
+    if (src != ZK_OK) return src;
+  }
+  if (!gens || !com_d || !value_h || !g1_h || !inf_h || !ok || (k && !u_h)) return ctx->fail(ZK_ERR_ARG, "zk_verify_open: null argument");
+  *ok = 0;
+  const uint32_t k_lo = ceil_log2(gens->n), k_hi = ceil_log2(m);
+  if (m == 0 || k != k_lo + k_hi || gens->n != (1u << k_lo) || n_g1 != 3 * (size_t)k_lo + 2) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
+  Fail fail{ctx, ok};
+  bool passed = false;
+  ZK_TRY(verify_opening(ctx, fail, gens, com_d, m, u_h, k, ld(value_h), g1_h, inf_h, &passed));
+  if (passed) *ok = 1;
   return ZK_OK;
 }
 

@@ -140,3 +140,80 @@ def verify_mlp(zk, dims, batch, gens, coms, x_fr, y_fr, blob, chal=None):
                 return False, "zkReLU layer %d: %s" % (i, msg), open_claims
             open_claims += [("relu_%d:%s" % (i, nm), c) for nm, c in zip(("mag_bin~(v_z)", "rem_bin~(v_r)", "(Z.sign)~(u_hp)", "Z~(v_hp)", "sign~(v_hp)"), claims)]
     return True, "", open_claims
+
+
+# ------------------------------------------------------------------ activation commitments (the reference's stated future work)
+# The layer proofs leave the activation-side evaluations as open claims (verify_mlp returns them): nothing in the reference's protocol
+# ties Z_i~(u), A_i~(u) to the tensors.  With the activations COMMITTED (the same row-wise Pedersen commitment the weights use:
+# zk_commit over the layer's generators) every such claim is closed by an opening (zk_open) that zk_verify_open checks against the
+# commitment -- and because FC_i's output claim, ReLU_i's input claim and FC_{i+1}'s input claim open the SAME commitments, the layers
+# are chained.  What stays open: the ReLU's bit / sign tensors (the reference's ReLU relation between Z, sign, the bits and A is itself
+# incomplete).  This is optional protocol work on top of the reference's proof: ~2^19-pair commitments and three extra openings per layer.
+def activation_claims(dims, batch, chal):
+    """[(tensor name, point u)] for every claim on a committed activation: FC_i opens Z_i at u_out||u_bs and A_{i-1} at u_in||u_bs,
+    ReLU_i's Hadamard sumcheck ends in Z_i at v_hp."""
+    L = len(dims) - 1
+    out = []
+    for kind, i, ch in chal:
+        if kind == "fc":
+            if i != L - 1:
+                out.append(("Z%d" % i, np.concatenate([ch[2], ch[0]])))
+            if i != 0:
+                out.append(("A%d" % (i - 1), np.concatenate([ch[1], ch[0]])))
+        else:
+            out.append(("Z%d" % i, ch[6]))
+    return out
+
+
+def commit_activations(zk, gens, Z, A):
+    """Commit every pre-activation Z_i and activation A_i (i < L-1) over layer i's generators.  Returns {name: (gens, tensor, commitment)}."""
+    out = {}
+    for i, (z, a) in enumerate(zip(Z, A)):
+        g = gens[i]
+        out["Z%d" % i] = (g, z, zk.commit(g, z))
+        out["A%d" % i] = (g, a, zk.commit(g, a))
+    return out
+
+
+def open_activations(zk, committed, claims):
+    """One zk_open per claim: [(name, value, affine points, infinity flags)]."""
+    out = []
+    for name, u in claims:
+        g, t, com = committed[name]
+        ret, com_eval, proof = zk.open(g, t, com, u)
+        aff, inf = zk.g1_to_affine(zk.upload(np.concatenate([com_eval.reshape(1, 36), proof])))
+        out.append((name, ret, aff, inf))
+    return out
+
+
+def verify_activation_openings(zk, commitments, claims, openings, claimed_values):
+    """commitments: {name: (gens, commitment points)} -- public.  claimed_values[j]: the evaluation the layer proofs claim for claims[j]
+    (from verify_mlp's open_claims).  Every opening must verify against its commitment and open exactly the claimed value."""
+    if len(openings) != len(claims) or len(claimed_values) != len(claims):
+        return False, "wrong number of openings"
+    for (name, u), (oname, value, aff, inf), want in zip(claims, openings, claimed_values):
+        if oname != name:
+            return False, "opening %s where %s was expected" % (oname, name)
+        if not np.array_equal(np.asarray(value).reshape(8), np.asarray(want).reshape(8)):
+            return False, "%s: the opened value differs from the layer proof's claim" % name
+        g, com = commitments[name]
+        ok, msg = zk.verify_open(g, com, u, value, aff, inf)
+        if not ok:
+            return False, "%s: %s" % (name, msg)
+    return True, ""
+
+
+def claimed_activation_values(dims, open_claims):
+    """verify_mlp's open_claims -> the values in activation_claims() order."""
+    L = len(dims) - 1
+    by = {k: v for k, v in open_claims}
+    out = []
+    for kind, i in call_order(L):
+        if kind == "fc":
+            if i != L - 1:
+                out.append(by["Z_%d~(u_out||u_bs)" % i])
+            if i != 0:
+                out.append(by["A_%d~(u_in||u_bs)" % (i - 1)])
+        else:
+            out.append(by["relu_%d:Z~(v_hp)" % i])
+    return out
