@@ -365,11 +365,13 @@ def main():
     # The first compute process on a freshly leased box runs ~12 % slow for its whole lifetime (5.2 vs 4.6 ms per proof over 20 steps;
     # any later process is not affected).  A 0.1 s helper (zkdl_amd/lib/gpu_touch: malloc, one kernel, exit) takes that role, BEFORE
     # this process -- or the ranks it spawns -- touch the GPU.  Setup work, like the commitments: not part of any timed region.
-    if "WORLD_SIZE" not in os.environ and args.launcher_selftest is None:
-        touch = os.path.join(ROOT, "zkdl_amd", "lib", "gpu_touch")
-        if os.path.exists(touch):
+    touch = os.path.join(ROOT, "zkdl_amd", "lib", "gpu_touch")
+    if args.launcher_selftest is None and os.path.exists(touch):
+        if "WORLD_SIZE" not in os.environ:        # this process is the only rank, or the parent of the ranks it spawns below
             for dev in range(max(1, args.gpus if not args.same_device else 1)):
                 subprocess.run([touch, str(dev)], timeout=60, check=False)
+        else:                                     # a rank under torch.distributed.run: its own device
+            subprocess.run([touch, "0" if args.same_device else os.environ.get("LOCAL_RANK", "0")], timeout=60, check=False)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
