@@ -36,10 +36,18 @@
 #include "layers.hpp"
 
 #include "dev_util.hpp"
+#include "fq28.hpp"
 
 namespace zk {
 
 static constexpr uint32_t MSM_CHUNK = 16;  // items per lane in k_msm_accum
+#ifndef ZK_ACCUM_INLINE
+#define ZK_ACCUM_INLINE 1
+#endif
+#ifndef ZK_ACCUM_WAVES
+#define ZK_ACCUM_WAVES 2
+#endif
+static constexpr bool ACCUM_INLINE = ZK_ACCUM_INLINE;
 
 // ------------------------------------------------------------------ window tables
 // jac[w*n + j] = 2^(c*w) * gens[j]
@@ -52,6 +60,20 @@ __global__ void __launch_bounds__(64) k_table_chain(const G1J* __restrict__ gens
     if (w + 1 < W)
       for (uint32_t i = 0; i < c; i++) P = g1_double(P);
   }
+}
+
+// window tables hold x * 2^392 mod p (the Montgomery domain of fq28.hpp) in the 12 x 32-bit layout: eight modular doublings
+// of the library's x * 2^384 mod p
+__global__ void __launch_bounds__(256) k_table_nform(G1A* __restrict__ pts, uint64_t total) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  G1A p = pts[i];
+#pragma unroll 1
+  for (int d = 0; d < 8; d++) {
+    p.x = fp_dbl(p.x);
+    p.y = fp_dbl(p.y);
+  }
+  pts[i] = p;
 }
 
 int gens_table(zk_ctx* ctx, zk_gens* g, uint32_t c, uint32_t W, const G1Table** out) {
@@ -71,6 +93,7 @@ int gens_table(zk_ctx* ctx, zk_gens* g, uint32_t c, uint32_t W, const G1Table** 
     ZK_ALLOC(ctx, jac, G1J, total);
     ZK_LAUNCH(ctx, "msm_table_build", 144ull * total, k_table_chain, dim3((g->n + 63) / 64), dim3(64), 0, (const G1J*)g->pts, g->n, c, W, jac.get());
     ZK_TRY(g1_to_affine_dev(ctx, jac.get(), (uint32_t)total, T.pts, T.inf));
+    ZK_LAUNCH(ctx, "msm_table_nform", 192ull * total, k_table_nform, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, T.pts, (uint64_t)total);
   }
   if (it != g->tables.end()) {
     // a wider table replaces a narrower one IN PLACE: queued jobs hold a pointer to this map node and
@@ -167,92 +190,112 @@ __device__ __forceinline__ uint32_t recode_digit(const Recoded& r, uint32_t c, u
 // Inside the MSM pipeline a point is (X, Y, ZZ, ZZZ) with x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2 (infinity: ZZ = 0):
 // a mixed addition costs 8M + 2S instead of madd-2007-bl's 7M + 4S and a full addition 12M + 2S instead of
 // 11M + 5S (EFD "xyzz": madd-2008-s, add-2008-s, dbl-2008-s-1).  Buckets, chunk partials and row/column sums
-// never leave the pipeline; the result goes back to Jacobian as (X*ZZ*ZZZ^2, Y*ZZ^3*ZZZ^2, ZZ*ZZZ) -- the same
-// group element, and the canonical (affine) form the transcript keeps is unaffected.
+// never leave the pipeline, so their coordinates live in the 14 x 28-bit lazily reduced form of fq28.hpp (a product is
+// 392 single-instruction MACs instead of 288 MAC + carry pairs; sums and differences are carry-free).  The result
+// goes back to Jacobian as (X*ZZ*ZZZ^2, Y*ZZ^3*ZZZ^2, ZZ*ZZZ), converted to the library's canonical 12 x 32-bit
+// Montgomery form on the way out -- the same group element, and the canonical (affine) form the transcript keeps
+// is unaffected.
+//
+// Bounds (units of p; "n" = normalised limbs).  Stored X < 18, Y < 6, ZZ, ZZZ < 2, all n.  Every product below has
+// operand values whose product is < 2^11 and limbs < 2^28 x 2^32 or < 2^29.6 x 2^29.6 (fq28.hpp), so it returns n, < 2.
 struct alignas(16) G1X {
-  Fp x, y, zz, zzz;
+  Fq x, y, zz, zzz;
 };
 __device__ __forceinline__ G1X g1x_zero() {
   G1X r;
-  r.x = fp_zero();
-  r.y = fp_one();
-  r.zz = fp_zero();
-  r.zzz = fp_zero();
+  r.x = fq_zero();
+  r.y = fq_one();
+  r.zz = fq_zero();
+  r.zzz = fq_zero();
   return r;
 }
+__device__ __forceinline__ bool g1x_is_zero(const G1X& a) { return fq_all_zero(a.zz); }
 __device__ __forceinline__ G1X g1x_double(const G1X& a) {
-  if (l_is_zero(a.zz)) return a;
-  Fp u = fp_dbl(a.y);
-  Fp v = fp_sqr(u);
-  Fp w = fp_mul(u, v);
-  Fp s_ = fp_mul(a.x, v);
-  Fp xx = fp_sqr(a.x);
-  Fp m = fp_add(fp_dbl(xx), xx);
+  if (g1x_is_zero(a)) return a;
+  Fq u = fq_add(a.y, a.y);                 // < 12, limbs < 2^29
+  Fq v = fq_sqr(u);
+  Fq w = fq_mul(u, v);
+  Fq s_ = fq_mul(a.x, v);
+  Fq xx = fq_sqr(a.x);
+  Fq m = fq_add(fq_add(xx, xx), xx);       // < 6, limbs < 2^29.6
   G1X o;
-  o.x = fp_sub(fp_sub(fp_sqr(m), s_), s_);
-  o.y = fp_sub(fp_mul(m, fp_sub(s_, o.x)), fp_mul(w, a.y));
-  o.zz = fp_mul(v, a.zz);
-  o.zzz = fp_mul(w, a.zzz);
+  o.x = fq_norm(fq_sub3<16>(fq_sqr(m), fq_zero(), s_));                          // m^2 - 2s: < 2 + 16
+  o.y = fq_norm(fq_sub<4>(fq_mul(m, fq_sub<36>(s_, o.x)), fq_mul(w, a.y)));      // < 2 + 4
+  o.zz = fq_mul(v, a.zz);
+  o.zzz = fq_mul(w, a.zzz);
   return o;
 }
-__device__ __forceinline__ G1X g1x_madd(const G1X& a, const G1A& b) {
-  if (l_is_zero(a.zz)) {
+// INL: the products inlined into the caller (the hot loop of k_msm_accum: no argument shuffling around ten calls) or
+// real calls (everywhere else: code size)
+template <bool INL>
+__device__ __forceinline__ Fq fq_mul_t(const Fq& a, const Fq& b) {
+  if constexpr (INL) return fq_mul_inl(a, b);
+  else return fq_mul(a, b);
+}
+template <bool INL>
+__device__ __forceinline__ Fq fq_sqr_t(const Fq& a) {
+  if constexpr (INL) return fq_sqr_inl(a);
+  else return fq_sqr(a);
+}
+// shared tail of the two additions: (u1, s1) the first point and (pd, r) = (u2 - u1, s2 - s1), pp = pd^2, zz/zzz the
+// products of the inputs' ZZ / ZZZ
+template <bool INL = false>
+__device__ __forceinline__ G1X g1x_add_tail(const Fq& u1, const Fq& s1, const Fq& pd, const Fq& r, const Fq& pp, const Fq& zz, const Fq& zzz) {
+  Fq ppp = fq_mul_t<INL>(pd, pp);
+  Fq q = fq_mul_t<INL>(u1, pp);
+  G1X o;
+  o.x = fq_norm(fq_sub3<16>(fq_sqr_t<INL>(r), ppp, q));                                          // r^2 - ppp - 2q: < 2 + 16 = 18
+  o.y = fq_norm(fq_sub<4>(fq_mul_t<INL>(r, fq_sub<36>(q, o.x)), fq_mul_t<INL>(s1, ppp)));        // < 2 + 4 = 6
+  o.zz = fq_mul_t<INL>(zz, pp);
+  o.zzz = fq_mul_t<INL>(zzz, ppp);
+  return o;
+}
+// b: affine table point, n-form, normalised, < 1
+template <bool INL = false>
+__device__ __forceinline__ G1X g1x_madd(const G1X& a, const Fq& bx, const Fq& by) {
+  if (g1x_is_zero(a)) {
     G1X o;
-    o.x = b.x;
-    o.y = b.y;
-    o.zz = fp_one();
-    o.zzz = fp_one();
+    o.x = bx;
+    o.y = by;
+    o.zz = fq_one();
+    o.zzz = fq_one();
     return o;
   }
-  Fp u2 = fp_mul(b.x, a.zz);
-  Fp s2 = fp_mul(b.y, a.zzz);
-  Fp pd = fp_sub(u2, a.x);
-  Fp r = fp_sub(s2, a.y);
-  if (l_is_zero(pd)) return l_is_zero(r) ? g1x_double(a) : g1x_zero();
-  Fp pp = fp_sqr(pd);
-  Fp ppp = fp_mul(pd, pp);
-  Fp q = fp_mul(a.x, pp);
-  G1X o;
-  o.x = fp_sub(fp_sub(fp_sub(fp_sqr(r), ppp), q), q);
-  o.y = fp_sub(fp_mul(r, fp_sub(q, o.x)), fp_mul(a.y, ppp));
-  o.zz = fp_mul(a.zz, pp);
-  o.zzz = fp_mul(a.zzz, ppp);
-  return o;
+  Fq u2 = fq_mul_t<INL>(bx, a.zz);
+  Fq s2 = fq_mul_t<INL>(by, a.zzz);
+  Fq pd = fq_sub<36>(u2, a.x);   // < 2 + 36, limbs < 2^29.6
+  Fq r = fq_sub<16>(s2, a.y);    // < 2 + 16
+  Fq pp = fq_sqr_t<INL>(pd);     // 38^2 p/R' + 1 < 1.6
+  if (fq_is_zero_mod_p(pp)) return fq_is_zero_mod_p(fq_sqr(r)) ? g1x_double(a) : g1x_zero();
+  return g1x_add_tail<INL>(a.x, a.y, pd, r, pp, a.zz, a.zzz);
 }
 __device__ __forceinline__ G1X g1x_add(const G1X& a, const G1X& b) {
-  if (l_is_zero(a.zz)) return b;
-  if (l_is_zero(b.zz)) return a;
-  Fp u1 = fp_mul(a.x, b.zz);
-  Fp u2 = fp_mul(b.x, a.zz);
-  Fp s1 = fp_mul(a.y, b.zzz);
-  Fp s2 = fp_mul(b.y, a.zzz);
-  Fp pd = fp_sub(u2, u1);
-  Fp r = fp_sub(s2, s1);
-  if (l_is_zero(pd)) return l_is_zero(r) ? g1x_double(a) : g1x_zero();
-  Fp pp = fp_sqr(pd);
-  Fp ppp = fp_mul(pd, pp);
-  Fp q = fp_mul(u1, pp);
-  G1X o;
-  o.x = fp_sub(fp_sub(fp_sub(fp_sqr(r), ppp), q), q);
-  o.y = fp_sub(fp_mul(r, fp_sub(q, o.x)), fp_mul(s1, ppp));
-  o.zz = fp_mul(fp_mul(a.zz, b.zz), pp);
-  o.zzz = fp_mul(fp_mul(a.zzz, b.zzz), ppp);
-  return o;
+  if (g1x_is_zero(a)) return b;
+  if (g1x_is_zero(b)) return a;
+  Fq u1 = fq_mul(a.x, b.zz);
+  Fq u2 = fq_mul(b.x, a.zz);
+  Fq s1 = fq_mul(a.y, b.zzz);
+  Fq s2 = fq_mul(b.y, a.zzz);
+  Fq pd = fq_sub<4>(u2, u1);
+  Fq r = fq_sub<4>(s2, s1);
+  Fq pp = fq_sqr(pd);
+  if (fq_is_zero_mod_p(pp)) return fq_is_zero_mod_p(fq_sqr(r)) ? g1x_double(a) : g1x_zero();
+  return g1x_add_tail(u1, s1, pd, r, pp, fq_mul(a.zz, b.zz), fq_mul(a.zzz, b.zzz));
 }
 __device__ __forceinline__ G1J g1x_to_jacobian(const G1X& a) {
-  if (l_is_zero(a.zz)) return g1_zero();
-  Fp z = fp_mul(a.zz, a.zzz);                 // Z = ZZ*ZZZ: Z^2 = ZZ^2 ZZZ^2, Z^3 = ZZ^3 ZZZ^3
-  Fp t = fp_mul(a.zz, fp_sqr(a.zzz));         // ZZ ZZZ^2
+  if (g1x_is_zero(a)) return g1_zero();
+  Fq z = fq_mul(a.zz, a.zzz);                 // Z = ZZ*ZZZ: Z^2 = ZZ^2 ZZZ^2, Z^3 = ZZ^3 ZZZ^3
+  Fq t = fq_mul(a.zz, fq_sqr(a.zzz));         // ZZ ZZZ^2
   G1J o;
-  o.x = fp_mul(a.x, t);                       // x Z^2 = X/ZZ * ZZ^2 ZZZ^2
-  o.y = fp_mul(a.y, fp_mul(t, fp_sqr(a.zz)));  // y Z^3 = Y/ZZZ * ZZ^3 ZZZ^3
-  o.z = z;
+  o.x = fq_to_fp(fq_mul(a.x, t));                       // x Z^2 = X/ZZ * ZZ^2 ZZZ^2
+  o.y = fq_to_fp(fq_mul(a.y, fq_mul(t, fq_sqr(a.zz))));  // y Z^3 = Y/ZZZ * ZZ^3 ZZZ^3
+  o.z = fq_to_fp(z);
   return o;
 }
 __device__ __forceinline__ G1X g1x_shfl_xor(const G1X& p, int mask) {
   G1X r;
 #pragma unroll
-  for (int i = 0; i < 12; i++) {
+  for (int i = 0; i < 14; i++) {
     r.x.v[i] = __shfl_xor(p.x.v[i], mask, 64);
     r.y.v[i] = __shfl_xor(p.y.v[i], mask, 64);
     r.zz.v[i] = __shfl_xor(p.zz.v[i], mask, 64);
@@ -339,7 +382,7 @@ __global__ void __launch_bounds__(1024) k_msm_sort(const MsmJob* __restrict__ jo
 // Each lane adds MSM_CHUNK consecutive items of the bucket-sorted list.  A bucket wholly inside the
 // chunk is stored to buckets[]; a bucket that started earlier goes to head[chunk], one that continues
 // later to tail[chunk].  grid (chunk blocks, jobs).
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) k_msm_accum(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ off,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZK_ACCUM_WAVES, ZK_ACCUM_WAVES))) k_msm_accum(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ off,
                                                    G1X* __restrict__ buckets, G1X* __restrict__ head, G1X* __restrict__ tail) {
   const uint32_t B = 1u << (c - 1);
   const uint32_t q = blockIdx.y;
@@ -379,7 +422,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
     uint32_t j = it & 0xfffffu, w = (it >> 20) & 0x7ffu;
     G1A P = job.table[(uint64_t)w * job.n + j];
     if (it >> 31) P.y = fp_neg(P.y);
-    acc = g1x_madd(acc, P);
+    acc = g1x_madd<ACCUM_INLINE>(acc, fq_unpack(P.x), fq_unpack(P.y));
   }
   // last run of the chunk: [run_start, ce) of bucket b
   bool starts = run_start == o[b], ends = ce == bend;
@@ -585,15 +628,15 @@ int msm_run_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs, uint32_t c) 
     const bool full = c * Wmax >= 254u;
     const bool hot = !full || 256u - c * (Wmax - 1) <= 4u || chunks > 12ull * nj * B;  // or simply many chunks per bucket
     if (hot)
-      ZK_LAUNCH(ctx, "msm_combine", 192ull * nj * B, k_msm_combine<4>, dim3((B + 15) / 16, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, (const uint32_t*)off.get(),
+      ZK_LAUNCH(ctx, "msm_combine", (uint64_t)sizeof(G1X) * nj * B, k_msm_combine<4>, dim3((B + 15) / 16, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, (const uint32_t*)off.get(),
                 buckets.get(), (const G1X*)head.get(), (const G1X*)tail.get());
     else
-      ZK_LAUNCH(ctx, "msm_combine", 192ull * nj * B, k_msm_combine<2>, dim3((B + 31) / 32, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, (const uint32_t*)off.get(),
+      ZK_LAUNCH(ctx, "msm_combine", (uint64_t)sizeof(G1X) * nj * B, k_msm_combine<2>, dim3((B + 31) / 32, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, (const uint32_t*)off.get(),
                 buckets.get(), (const G1X*)head.get(), (const G1X*)tail.get());
   }
   const ReduceShape sh = reduce_shape(c);
-  ZK_LAUNCH(ctx, "msm_bucket_reduce", 192ull * nj * B, k_msm_rowcol, dim3((sh.nsums * 4 + 63) / 64, nj), dim3(64), 0, (const G1X*)buckets.get(), c, sh, RC.get());
-  ZK_LAUNCH(ctx, "msm_horner", 192ull * nj * sh.nsums, k_msm_weighted, dim3(nj), dim3(64), 0, (const MsmJob*)djobs.get(), (const G1X*)RC.get(), c, sh);
+  ZK_LAUNCH(ctx, "msm_bucket_reduce", (uint64_t)sizeof(G1X) * nj * B, k_msm_rowcol, dim3((sh.nsums * 4 + 63) / 64, nj), dim3(64), 0, (const G1X*)buckets.get(), c, sh, RC.get());
+  ZK_LAUNCH(ctx, "msm_horner", (uint64_t)sizeof(G1X) * nj * sh.nsums, k_msm_weighted, dim3(nj), dim3(64), 0, (const MsmJob*)djobs.get(), (const G1X*)RC.get(), c, sh);
   return ZK_OK;
 }
 
