@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 MLP18M = [784, 1000, 1773, 1773, 1773, 1773, 1773, 1124, 1000]      # model.py:14-30
-WORKLOADS = {"mlp18m_b256": (MLP18M, 256), "mlp18m_b1": (MLP18M, 1), "tiny": ([64, 96, 48, 32], 16),
+WORKLOADS = {"mlp18m_b256": (MLP18M, 256), "mlp18m_b512": (MLP18M, 512), "mlp18m_b1024": (MLP18M, 1024), "mlp18m_b1": (MLP18M, 1), "tiny": ([64, 96, 48, 32], 16),
              "deep4096x64_b256": ([4096] * 65, 256), "deep4096x8_b256": ([4096] * 9, 256)}   # BASELINE configs[4] (a parity/stress case, not the bench line)
 R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
@@ -129,6 +129,7 @@ class Workload:
         """Fresh challenge vectors in the reference's draw order (zkfc.cu:135-137, zkrelu.cu:85-98)."""
         zk, sh, L = self.zk, self.shapes, len(self.shapes)
         kb = ceil_log2(self.B_p)
+        zk.seed(0xC0FFEE + (step & 0xffffff))    # a function of the step alone: the run aggregate does not depend on how many spin-up proofs ran
 
         def fc(s):
             return [zk.random_vec(kb), zk.random_vec(ceil_log2(s["in_p"])), zk.random_vec(ceil_log2(s["out_p"]))]
@@ -345,7 +346,9 @@ def main():
     ap.add_argument("--spinup-ms", type=float, default=400.0, help="untimed proofs before the W warm-up steps until this much wall time has passed: the first process on a "
                     "fresh box otherwise runs its first ~100 ms 12 %% slow (GPU power state); 0 disables")
     ap.add_argument("--prof-steps", type=int, default=2, help="proofs per event-profiled pass after the timed region (ZKDL_PROF_TRACE=<file> writes their per-launch timeline)")
-    ap.add_argument("--inflight", type=int, default=5, help="transcripts rotated by the pipelined loop (proofs whose G1 phase may still be running)")
+    ap.add_argument("--pair", type=int, default=1, choices=[1, 2], help="proofs submitted together (zk_transcript_seal_pair): 2 = the Fr phases of two consecutive "
+                    "proofs share their launches; every proof is still its own batch-256 proof with its own transcript and digest row")
+    ap.add_argument("--inflight", type=int, default=3, help="transcripts rotated by the pipelined loop (proofs whose G1 phase may still be running)")
     ap.add_argument("--no-derive", action="store_true", help="run every round commitment T_r of the openings as an MSM (library default) instead of deriving T_1.. from the "
                     "folding relation behind the MSM batch (the throughput configuration: -31 %% msm_accum work, a ~6 ms longer G1 phase per proof)")
     ap.add_argument("--serial", action="store_true", help="no worker streams at all: every launch runs alone (the schedule the roofline durations are measured under)")
@@ -441,6 +444,15 @@ def main():
         else:
             tr.digest_dev(row_ptr)
 
+    paired = pipelined and args.pair == 2 and len(wl.trs) >= 2
+
+    def step2(i, row_ptr, j, row_ptr_j):
+        """proofs i and j recorded on two transcripts, then submitted together"""
+        ta, tb = wl.trs[i % len(wl.trs)], wl.trs[j % len(wl.trs)]
+        wl.prove(wl.challenges(i), ta)
+        wl.prove(wl.challenges(j), tb)
+        ta.seal_pair(tb, row_ptr, row_ptr_j)
+
     def barrier():
         zk.sync()
         torch.cuda.synchronize()
@@ -455,11 +467,17 @@ def main():
         if n_spin % 8 == 0:
             zk.sync()                            # do not let the host run ahead of the device during the spin-up
     zk.sync()
-    for i in range(args.warmup):
-        # the warm-up also runs one proof in the drain configuration (see below), so that the allocator pools hold blocks of both shapes
-        if derive and args.warmup >= 2 and i == args.warmup - 2:
+    i = 0
+    while i < args.warmup:
+        # the warm-up also runs proofs in the drain configuration (see below), so that the allocator pools hold blocks of both shapes
+        if derive and args.warmup >= 2 and i >= args.warmup - 2:
             zk.lib.zk_set_flag(zk.ctx, b"derive_rounds", 0)
-        step(-1 - i, scratch_base + 64 * i)
+        if paired and i + 1 < args.warmup:
+            step2(-1 - i, scratch_base + 64 * i, -2 - i, scratch_base + 64 * (i + 1))
+            i += 2
+        else:
+            step(-1 - i, scratch_base + 64 * i)
+            i += 1
         if derive:
             zk.lib.zk_set_flag(zk.ctx, b"derive_rounds", 1)
     if world > 1:                                # warm the communicator outside the timed region
@@ -475,10 +493,16 @@ def main():
     # the pipeline then drains in one MSM chain instead of two.
     drain_from = args.steps - 3 if derive else args.steps
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        if i == drain_from:
+    i = 0
+    while i < args.steps:
+        if derive and i >= drain_from:
             zk.lib.zk_set_flag(zk.ctx, b"derive_rounds", 0)
-        step(i, rows_base + 64 * i)
+        if paired and i + 1 < args.steps:
+            step2(i, rows_base + 64 * i, i + 1, rows_base + 64 * (i + 1))
+            i += 2
+        else:
+            step(i, rows_base + 64 * i)
+            i += 1
     t_enq = time.perf_counter() - t0          # host time to enqueue K steps (no device wait inside)
     zk.sync()                                 # all G1 streams joined: every row is final
     agg = rows[:args.steps].sum(dim=0)        # < K * 2^32 per lane: exact in int64
@@ -498,6 +522,8 @@ def main():
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
     value = ms_per_step / (batch * world)
     aggregate = lanes_to_fr(agg.cpu().tolist())
+    if os.environ.get("ZKDL_BENCH_DUMP_ROWS"):       # per-proof digests, for run-to-run comparisons
+        np.save(os.environ["ZKDL_BENCH_DUMP_ROWS"], rows[:args.steps].cpu().numpy())
 
     # ---- per-kernel device time (HIP events on the launching stream).  Two passes over the same steps:
     #  * standalone: worker streams off, so every launch runs alone on the chip -- this is the duration a
@@ -557,6 +583,8 @@ def main():
     pmc_all = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
     cands = [k for k in kernels if k in macs_per_launch] or list(kernels)[:1]
     dom = max(cands, key=lambda k: kernels[k]["ms_per_step"])
+    if "msm_accum" in cands and kernels["msm_accum"]["ms_per_step"] >= 0.7 * kernels[dom]["ms_per_step"]:
+        dom = "msm_accum"   # the one launch that fills the chip; the sumcheck families are 18 small launches each (their rates are under other_kernels_TMACps)
     pv = prof[dom]
     avg_ms = pv["ms"] / max(pv["launches"], 1)
     hbm_achieved = pv["bytes"] / pv["ms"] / 1e6 if pv["ms"] > 0 else 0.0
@@ -583,7 +611,7 @@ def main():
            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (Fr) / u32x12 (Fp) limbs",
            "data": "synthetic",
            "config": {"workload": args.workload, "dims": dims, "batch_per_gpu": batch, "parallelism": "independent proofs per rank, one RCCL all-reduce of the run aggregate",
-                      "msm": args.msm, "derive_rounds": bool(derive), "inflight": args.inflight},
+                      "msm": args.msm, "derive_rounds": bool(derive), "inflight": args.inflight, "proofs_per_submission": 2 if paired else 1},
            "ms_per_proof": ms_per_step, "per_rank_ms_per_proof": per_rank_ms, "collective_world_size": (dist.get_world_size() if world > 1 else 1),
            "collective_backend": (dist.get_backend() if world > 1 else None),
            "host_enqueue_ms_per_step": t_enq * 1e3 / max(args.steps, 1), "aggregate_fr": hex(aggregate), "setup": wl.info, "roofline": roofline, "kernels": kernels,

@@ -247,6 +247,11 @@ int zk_transcript_serialize(zk_transcript* tr, void* buf_h, size_t cap, size_t* 
  * waits for the sealed phase first; work that consumes out8_d must be ordered on zk_transcript_stream(tr).
  * Without worker lanes this degrades to flush + digest_dev on the main stream (same values). */
 int zk_transcript_seal(zk_transcript* tr, uint64_t* out8_d);
+/* Two proofs submitted together: same values as zk_transcript_seal(a, ..) followed by zk_transcript_seal(b, ..), but the recorded
+ * Fr work of both runs as ONE set of batched launches (each launch carries the jobs of both proofs), then each proof's G1 phase
+ * goes to its own G1 stream.  No reference counterpart (the reference proves one batch at a time, synchronously); throughput
+ * only: a proof's latency grows by its partner's Fr phase. */
+int zk_transcript_seal_pair(zk_transcript* a, uint64_t* a_out8_d, zk_transcript* b, uint64_t* b_out8_d);
 /* the hipStream_t the last zk_transcript_seal of this transcript was enqueued on (the main stream if it ran
  * synchronously or was never sealed) */
 void* zk_transcript_stream(zk_transcript* tr);

@@ -33,7 +33,7 @@ zk_set_msm_window zk_set_flag zk_gens_create zk_gens_destroy zk_gens_size zk_gen
 zk_fc_out zk_fc_com_size zk_fc_weights zk_fc_com zk_fc_load_input zk_fc_forward zk_fc_prove zk_relu_create
 zk_relu_destroy zk_relu_forward zk_relu_sign zk_relu_mag_bin zk_relu_rem_bin zk_relu_prove zk_transcript_create
 zk_transcript_destroy zk_transcript_reset zk_transcript_flush zk_transcript_counts zk_transcript_read zk_transcript_read_affine
-zk_transcript_digest zk_transcript_digest_dev zk_transcript_serialize zk_transcript_seal zk_transcript_stream
+zk_transcript_digest zk_transcript_digest_dev zk_transcript_serialize zk_transcript_seal zk_transcript_seal_pair zk_transcript_stream
 zk_verify_fc zk_verify_relu zk_verify_open zk_fs_derive zk_sha256""".split()
 
 
@@ -584,6 +584,10 @@ class Transcript:
     def seal(self, out8_ptr=None):
         """Finish the proof on the G1 stream without making the main stream wait (zk_transcript_seal)."""
         self.zk._chk(self.zk.lib.zk_transcript_seal(self.h, _vp(out8_ptr) if out8_ptr else None))
+
+    def seal_pair(self, other, out8_ptr=None, other_out8_ptr=None):
+        """This proof and `other` submitted together: one zipped Fr phase, two G1 phases (zk_transcript_seal_pair)."""
+        self.zk._chk(self.zk.lib.zk_transcript_seal_pair(self.h, _vp(out8_ptr) if out8_ptr else None, other.h, _vp(other_out8_ptr) if other_out8_ptr else None))
 
     def stream(self):
         """hipStream_t (as int) the last seal() was enqueued on."""

@@ -152,7 +152,7 @@ int zk_ctx_create(int device, zk_ctx** out) {
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     int prio = g1_prio < 0 ? least : g1_prio > 0 ? greatest : (least + greatest) / 2;
     {
-      int ng = 4;  // 2 suffice without derived round commitments; with them a sealed proof's G1 phase is ~11 ms long (sched sweeps: DESIGN.md sec.10)
+      int ng = 2;  // a sealed proof's G1 phase is ~7 ms long (derived round commitments on the 28-bit-limb field); 3 or 4 streams measure slower
       if (const char* e = getenv("ZKDL_G1_STREAMS")) ng = atoi(e);
       ng = ng < 0 ? 0 : ng > 8 ? 8 : ng;
       ctx->g1_lanes.resize((size_t)ng);
@@ -815,6 +815,11 @@ int zk_transcript_seal(zk_transcript* tr, uint64_t* out8_d) {
   if (!tr) return ZK_ERR_ARG;
   if (out8_d && (((uintptr_t)out8_d) & 7u)) return tr->ctx->fail(ZK_ERR_ARG, "misaligned pointer: out8_d");
   return tr->seal(out8_d);
+}
+int zk_transcript_seal_pair(zk_transcript* a, uint64_t* a_out8_d, zk_transcript* b, uint64_t* b_out8_d) {
+  if (!a || !b) return ZK_ERR_ARG;
+  if ((a_out8_d && (((uintptr_t)a_out8_d) & 7u)) || (b_out8_d && (((uintptr_t)b_out8_d) & 7u))) return a->ctx->fail(ZK_ERR_ARG, "misaligned pointer: out8_d");
+  return a->seal_pair(b, a_out8_d, b_out8_d);
 }
 void* zk_transcript_stream(zk_transcript* tr) { return tr ? (void*)(tr->sealed_stream ? tr->sealed_stream : tr->ctx->main_stream) : nullptr; }
 int zk_transcript_counts(zk_transcript* tr, size_t* n_fr, size_t* n_g1) {

@@ -50,7 +50,7 @@ ZK_HD constexpr uint32_t ONE(int i) {
 }
 // K*p arranged for carry-free subtraction of NSUB normalised values: limb i < 13 carries an extra NSUB * 2^28 borrowed
 // from limb i+1, so that  a.v[i] + C.v[i] - b1.v[i] - ... never goes negative.  Needs K*p's top limb - NSUB to cover the
-// subtrahends' top limbs: K >= 2 * (sum of the subtrahends' value bounds, in units of p) is enough.
+// subtrahends' top limbs: K >= (sum of the subtrahends' value bounds, in units of p) + 1 is enough (p's top limb is ~10^5).
 struct SubConst {
   uint32_t v[14];
 };
@@ -223,6 +223,24 @@ __device__ __forceinline__ Fq fq_sub3(const Fq& a, const Fq& b, const Fq& c) {
   for (int i = 0; i < 14; i++) r.v[i] = a.v[i] - b.v[i] - (c.v[i] << 1) + C.v[i];
   return r;
 }
+// a + K p - b - c  (b, c normalised, value(b) + value(c) < K p)
+template <uint32_t K>
+__device__ __forceinline__ Fq fq_sub2(const Fq& a, const Fq& b, const Fq& c) {
+  constexpr fq28::SubConst C = fq28::sub_const(K, 2);
+  Fq r;
+#pragma unroll
+  for (int i = 0; i < 14; i++) r.v[i] = a.v[i] - b.v[i] - c.v[i] + C.v[i];
+  return r;
+}
+// a + K p - 8 c  (c normalised, 8 value(c) < K p): limbs < max_limb(a) + 2^31 + 2^28
+template <uint32_t K>
+__device__ __forceinline__ Fq fq_sub8(const Fq& a, const Fq& c) {
+  constexpr fq28::SubConst C = fq28::sub_const(K, 8);
+  Fq r;
+#pragma unroll
+  for (int i = 0; i < 14; i++) r.v[i] = a.v[i] - (c.v[i] << 3) + C.v[i];
+  return r;
+}
 // carry the limbs back under 2^28 (value unchanged)
 __device__ __forceinline__ Fq fq_norm(const Fq& a) {
   Fq r;
@@ -271,6 +289,30 @@ __device__ __forceinline__ Fp fq_to_fp(const Fq& a) {
 #pragma unroll
   for (int i = 0; i < 14; i++) c.v[i] = fq28::C384(i);
   return f_reduce_once<FpP>(fq_pack(fq_mul(a, c)));  // a * 2^384 / 2^392 = a / 2^8, < 2p
+}
+
+// canonical o-form (x 2^384 mod p, 12 x 32 bits) -> n-form: the way into the pipeline for values that do not come from a window table
+__device__ __forceinline__ Fq fq_from_fp(const Fp& a) {
+  constexpr uint32_t c400[14] = {135160473u, 55574580u, 246491222u, 233514649u, 211322480u, 82798231u, 118064104u,
+                                 172912617u, 65577043u, 248456990u, 203477795u, 116089733u, 75436678u, 87770u};  // 2^400 mod p
+  Fq c;
+#pragma unroll
+  for (int i = 0; i < 14; i++) c.v[i] = c400[i];
+  return fq_mul(fq_unpack(a), c);  // a 2^400 / 2^392 = a 2^8
+}
+// a^(p-2), a normalised and < 2^5 p (Fermat inverse; backs the affine-canonical form, see field.hpp:fp_inv)
+__device__ __forceinline__ Fq fq_inv(const Fq& a) {
+  Fq acc = fq_one();
+#pragma unroll 1
+  for (int i = 12 * 32 - 1; i >= 0; i--) {
+    uint32_t limb = FpP::P(0);
+#pragma unroll
+    for (int j = 1; j < 12; j++) limb = ((i >> 5) == j) ? FpP::P(j) : limb;
+    if ((i >> 5) == 0) limb -= 2u;
+    acc = fq_sqr(acc);
+    if ((limb >> (i & 31)) & 1u) acc = fq_mul(acc, a);
+  }
+  return acc;
 }
 
 }  // namespace zk

@@ -87,7 +87,7 @@ struct Recorder {
   std::vector<void*> held_free;            // temporaries of an UNJOINED execution: released when the owner knows the lanes are done
   bool empty() const { return chains.empty(); }
 };
-static constexpr size_t REC_BLOB_CAP = 4u << 20;
+static constexpr size_t REC_BLOB_CAP = 8u << 20;
 // groups (= streams) the layers' independent pieces are spread over, balanced on the 18M-parameter MLP:
 // FC sumcheck + Z(u) + ReLU partial_me's | FC opening + ReLU Hadamard sumcheck | ReLU magnitude bits | ReLU remainder bits
 enum { REC_GROUP_FC_A = 0, REC_GROUP_FC_OPEN = 1, REC_GROUP_RELU_MAG = 2, REC_GROUP_RELU_REM = 3 };
@@ -97,6 +97,7 @@ void rec_split(zk_ctx* ctx, uint32_t group);              // recording: what fol
 void rec_end_chain(zk_ctx* ctx);                           // clears ctx->rec
 void rec_rollback(zk_ctx* ctx, Recorder* r, size_t keep_chains);  // a recording prove call failed: drop its chains
 int rec_execute(zk_ctx* ctx, Recorder* r, bool join = true);  // zip + launch on ctx->stream; join: home waits for the groups, temporaries released
+int rec_merge(zk_ctx* ctx, Recorder* dst, Recorder* src);  // src's chains join dst's: one execution zips both
 void rec_release_held(zk_ctx* ctx, Recorder* r);           // after an unjoined execution, once every group stream is known to be ordered before the caller
 void* rec_blob_put(zk_ctx* ctx, const void* src, size_t bytes);  // -> DEVICE address inside the blob
 int rec_opaque(zk_ctx* ctx, const char* name, uint64_t bytes, std::function<int(hipStream_t)> fn);

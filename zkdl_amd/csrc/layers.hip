@@ -287,6 +287,28 @@ int zk_transcript::seal(uint64_t* out8_d) {
   // the main stream: the next proof's groups queue behind this proof's, stream by stream, so a short group no longer idles until
   // the longest one is done (the temporaries then stay with the recorder until unseal()).
   ZK_TRY(rec_execute(ctx, &rec, /*join=*/!ctx->pipeline_fr));
+  return g1_phase(out8_d);
+}
+
+// Two proofs recorded on two transcripts, submitted together: their Fr chains are zipped into the same launches (a proof's Fr phase
+// is ~80 mostly latency-bound launches; two proofs share them), then each proof's G1 phase goes to its own G1 stream as in seal().
+// Same values as two seal() calls.  The temporaries of both Fr phases stay with THIS transcript's recorder until it is unsealed.
+int zk_transcript::seal_pair(zk_transcript* other, uint64_t* out8_d, uint64_t* other_out8_d) {
+  if (!other || other == this || other->ctx != ctx) return ctx->fail(ZK_ERR_ARG, "seal_pair: needs two transcripts of one context");
+  if (ctx->g1_lanes.empty() || !ctx->lanes_enabled || ctx->stream != ctx->main_stream) {
+    ZK_TRY(seal(out8_d));
+    return other->seal(other_out8_d);
+  }
+  unseal();
+  other->unseal();
+  ZK_TRY(rec_merge(ctx, &rec, &other->rec));
+  ZK_TRY(rec_execute(ctx, &rec, /*join=*/!ctx->pipeline_fr));
+  ZK_TRY(rec_execute(ctx, &other->rec, /*join=*/!ctx->pipeline_fr));  // only when there was nothing to merge into
+  ZK_TRY(g1_phase(out8_d));
+  return other->g1_phase(other_out8_d);
+}
+
+int zk_transcript::g1_phase(uint64_t* out8_d) {
   zk_ctx::Lane& g = ctx->g1_lanes[ctx->next_g1++ % ctx->g1_lanes.size()];
   sealed_stream = g.stream;
   if (!sealed_ev && hipEventCreateWithFlags(&sealed_ev, hipEventDisableTiming) != hipSuccess) return ctx->fail(ZK_ERR_DEVICE, "hipEventCreate failed");

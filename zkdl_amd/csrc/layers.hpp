@@ -81,6 +81,8 @@ struct zk_transcript {  // proof values in the order of SURVEY.md App. A.6, resi
   hipStream_t sealed_stream = nullptr;  // where the last seal ran (nullptr: main stream)
   int flush();                      // run pending MSMs on the main stream, canonicalise their outputs
   int seal(uint64_t* out8_d);       // the same plus the digest, on the G1 stream, with no main-stream wait
+  int seal_pair(zk_transcript* other, uint64_t* out8_d, uint64_t* other_out8_d);  // two proofs: ONE zipped Fr phase, then each one's G1 phase
+  int g1_phase(uint64_t* out8_d);   // the part of seal() after the Fr phase
   void unseal();                    // main stream waits for a sealed G1 phase; its scalars are released
 };
 

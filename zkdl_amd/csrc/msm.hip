@@ -37,6 +37,7 @@
 
 #include "dev_util.hpp"
 #include "fq28.hpp"
+#include "g1q.hpp"
 
 namespace zk {
 
@@ -548,15 +549,8 @@ __global__ void __launch_bounds__(64) k_g1_canonicalise(G1J* __restrict__ pts, u
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   G1J p = pts[i];
-  G1J r = g1_zero();
-  if (!l_is_zero(p.z)) {
-    if (l_eq(p.z, fp_one())) return;
-    Fp zi = fp_inv(p.z), zi2 = fp_sqr(zi);
-    r.x = fp_mul(p.x, zi2);
-    r.y = fp_mul(p.y, fp_mul(zi2, zi));
-    r.z = fp_one();
-  }
-  pts[i] = r;
+  if (!l_is_zero(p.z) && l_eq(p.z, fp_one())) return;
+  pts[i] = g1q_canonical(g1q_from_jacobian(p));  // the inversion's ~570 dependent products in the 28-bit-limb form (g1q.hpp)
 }
 int g1_canonicalise_dev(zk_ctx* ctx, G1J* pts, uint32_t n) {
   if (n) ZK_LAUNCH(ctx, "g1_canonicalise", 288ull * n, k_g1_canonicalise, dim3((n + 63) / 64), dim3(64), 0, pts, n);
@@ -775,7 +769,7 @@ struct DeriveJob {
 // k = sum_i d_i 16^i (no carries between digits: the same recoding as the bucket MSM's), so the lane keeps P .. 8P in a private
 // slice of `tab` (global, L2-resident) and runs 63 x (4 doublings + 1 addition): 252 doublings + ~71 additions instead of the 256 +
 // ~128 of the bitwise ladder -- this kernel is ONE wave's latency per lane, nothing else.
-__device__ __forceinline__ G1J g1_mul_w4(const G1J& P, const Fr& k, G1J* __restrict__ tab) {
+__device__ __forceinline__ G1Q g1q_mul_w4(const G1Q& P, const Fr& k, G1Q* __restrict__ tab) {
   // t = k + K, K = 0x888...8 (64 nibbles): 9 limbs
   uint32_t t[9];
   uint32_t carry = 0;
@@ -787,13 +781,13 @@ __device__ __forceinline__ G1J g1_mul_w4(const G1J& P, const Fr& k, G1J* __restr
   }
   t[8] = carry;  // digit 64: 0 or 1 (its "+8" was not added: plain digit)
   tab[0] = P;
-  G1J acc = g1_double(P);
+  G1Q acc = g1q_double(P);
   tab[1] = acc;
   for (int i = 2; i < 8; i++) {
-    acc = g1_add(acc, P);
+    acc = g1q_add(acc, P);
     tab[i] = acc;
   }
-  acc = t[8] ? P : g1_zero();
+  acc = t[8] ? P : g1q_zero();
 #pragma unroll 1
   for (int w = 7; w >= 0; w--) {
     uint32_t limb = t[0];
@@ -801,19 +795,20 @@ __device__ __forceinline__ G1J g1_mul_w4(const G1J& P, const Fr& k, G1J* __restr
     for (int i = 1; i < 8; i++) limb = (w == i) ? t[i] : limb;
 #pragma unroll 1
     for (int nb = 7; nb >= 0; nb--) {
-      acc = g1_double(g1_double(g1_double(g1_double(acc))));
+#pragma unroll 1
+      for (int d4 = 0; d4 < 4; d4++) acc = g1q_double(acc);
       const int d = (int)((limb >> (4 * nb)) & 15u) - 8;
       if (d != 0) {
-        G1J q = tab[(d < 0 ? -d : d) - 1];
-        if (d < 0) q.y = fp_neg(q.y);
-        acc = g1_add(acc, q);
+        G1Q q = tab[(d < 0 ? -d : d) - 1];
+        if (d < 0) q = g1q_neg(q);
+        acc = g1q_add(acc, q);
       }
     }
   }
   return acc;
 }
 // one lane per (job, r, s): tmp[lane] = coef * point
-__global__ void __launch_bounds__(64) k_derive_mul(const DeriveJob* __restrict__ jobs, uint32_t nj, uint32_t total, G1J* __restrict__ tmp, G1J* __restrict__ tabs) {
+__global__ void __launch_bounds__(64) k_derive_mul(const DeriveJob* __restrict__ jobs, uint32_t nj, uint32_t total, G1Q* __restrict__ tmp, G1Q* __restrict__ tabs) {
   const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= total) return;
   uint32_t q = 0;
@@ -824,18 +819,19 @@ __global__ void __launch_bounds__(64) k_derive_mul(const DeriveJob* __restrict__
   while ((r + 1) * (r + 1) <= idx) r++;
   const uint32_t s = idx - r * r;
   const G1J P = s == 0 ? *job.base : job.proof[3u * ((s - 1) >> 1) + ((s & 1u) ? 1u : 2u)];
-  tmp[lane] = g1_mul_w4(P, job.coef[idx], tabs + (size_t)lane * 8);
+  tmp[lane] = g1q_mul_w4(g1q_from_jacobian(P), job.coef[idx], tabs + (size_t)lane * 8);
 }
 // one lane per (job, r): proof[3r] = sum of its 2r + 1 products
-__global__ void __launch_bounds__(64) k_derive_sum(const DeriveJob* __restrict__ jobs, uint32_t nj, uint32_t nseg, const uint32_t* __restrict__ seg_job, const G1J* __restrict__ tmp) {
+__global__ void __launch_bounds__(64) k_derive_sum(const DeriveJob* __restrict__ jobs, uint32_t nj, uint32_t nseg, const uint32_t* __restrict__ seg_job, const G1Q* __restrict__ tmp) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nseg) return;
   const uint32_t q = seg_job[2 * t], r = seg_job[2 * t + 1];
   const DeriveJob job = jobs[q];
-  const G1J* p = tmp + job.lane_off + (r * r - job.r0);
-  G1J acc = p[0];
-  for (uint32_t s = 1; s < 2 * r + 1; s++) acc = g1_add(acc, p[s]);
-  job.proof[3 * r] = acc;
+  const G1Q* p = tmp + job.lane_off + (r * r - job.r0);
+  G1Q acc = p[0];
+#pragma unroll 1
+  for (uint32_t s = 1; s < 2 * r + 1; s++) acc = g1q_add(acc, p[s]);
+  job.proof[3 * r] = g1q_to_jacobian(acc);
 }
 int msm_run_derives(zk_ctx* ctx, const std::vector<DeriveJobHost>& derives) {
   if (derives.empty()) return ZK_OK;
@@ -858,8 +854,8 @@ int msm_run_derives(zk_ctx* ctx, const std::vector<DeriveJobHost>& derives) {
   const uint32_t nj = (uint32_t)jobs.size(), nseg = (uint32_t)seg.size() / 2;
   ZK_ALLOC(ctx, djobs, DeriveJob, nj);
   ZK_ALLOC(ctx, dseg, uint32_t, seg.size());
-  ZK_ALLOC(ctx, tmp, G1J, total);
-  ZK_ALLOC(ctx, tabs, G1J, (size_t)total * 8);
+  ZK_ALLOC(ctx, tmp, G1Q, total);
+  ZK_ALLOC(ctx, tabs, G1Q, (size_t)total * 8);
   {
     void* st = ctx->stage_put(jobs.data(), jobs.size() * sizeof(DeriveJob));
     if (!st) return ctx->fail(ZK_ERR_ALLOC, "pinned staging exhausted");
@@ -869,7 +865,7 @@ int msm_run_derives(zk_ctx* ctx, const std::vector<DeriveJobHost>& derives) {
     ZK_TRY(dev_copy(ctx, dseg.get(), st, (seg.size() * 4 + 15) & ~(size_t)15));
   }
   ZK_LAUNCH(ctx, "msm_derive", 320ull * total, k_derive_mul, dim3((total + 63) / 64), dim3(64), 0, (const DeriveJob*)djobs.get(), nj, total, tmp.get(), tabs.get());
-  ZK_LAUNCH(ctx, "msm_derive", 144ull * total, k_derive_sum, dim3((nseg + 63) / 64), dim3(64), 0, (const DeriveJob*)djobs.get(), nj, nseg, (const uint32_t*)dseg.get(), (const G1J*)tmp.get());
+  ZK_LAUNCH(ctx, "msm_derive", 144ull * total, k_derive_sum, dim3((nseg + 63) / 64), dim3(64), 0, (const DeriveJob*)djobs.get(), nj, nseg, (const uint32_t*)dseg.get(), (const G1Q*)tmp.get());
   return ZK_OK;
 }
 

@@ -213,6 +213,38 @@ int rec_execute(zk_ctx* ctx, Recorder* r, bool join) {
   return rc;
 }
 
+// Move every recorded chain of `src` into `dst`, so that ONE rec_execute(dst) zips the launches of both (two proofs recorded on two
+// transcripts: every batched launch then carries the jobs of both, and the latency-bound small launches of a proof are shared).
+// src's uploads already have their device addresses inside src's blob: it is uploaded here and travels with dst's temporaries.
+int rec_merge(zk_ctx* ctx, Recorder* dst, Recorder* src) {
+  if (src->chains.empty()) return ZK_OK;
+  if (dst->chains.empty()) return ZK_OK;  // nothing to zip with: the caller executes src on its own
+  const size_t base = dst->args.size();
+  dst->args.insert(dst->args.end(), src->args.begin(), src->args.end());
+  for (auto& c : src->chains) {
+    for (auto& op : c.ops)
+      if (op.k) op.args_off += base;
+    dst->chains.push_back(std::move(c));
+  }
+  int rc = ZK_OK;
+  const size_t total = src->blob.size(), step = 1u << 20;
+  for (size_t o = 0; o < total && rc == ZK_OK; o += step) {
+    size_t nb = std::min(step, total - o);
+    void* st = ctx->stage_put(src->blob.data() + o, nb);
+    rc = st ? dev_copy(ctx, src->blob_dev + o, st, (nb + 15) & ~(size_t)15) : ctx->fail(ZK_ERR_ALLOC, "pinned staging exhausted");
+  }
+  if (src->blob_dev) dst->deferred_free.push_back(src->blob_dev);
+  for (void* p : src->deferred_free) dst->deferred_free.push_back(p);
+  src->blob_dev = nullptr;
+  src->deferred_free.clear();
+  src->chains.clear();
+  src->args.clear();
+  src->blob.clear();
+  auto it = std::find(ctx->pending_recs.begin(), ctx->pending_recs.end(), src);
+  if (it != ctx->pending_recs.end()) ctx->pending_recs.erase(it);
+  return rc;
+}
+
 void rec_release_held(zk_ctx* ctx, Recorder* r) {
   for (void* p : r->held_free) ctx->pool_release(p);
   r->held_free.clear();

@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include "ctx.hpp"
 #include "dev_util.hpp"
+#include "fs29.hpp"
 
 namespace zk {
 
@@ -187,6 +188,171 @@ __device__ __forceinline__ void k_sc_round(uint32_t zk_nblk, const Fr* __restric
   }
 }
 
+// ---- One big round in the 29-bit-limb arithmetic of fs29.hpp: the same coefficients, folded tables and partials layout as
+// k_sc_round<MODE, 1>, with
+//   * every product a single-instruction-MAC column scan (fs_mul) and every sum / difference carry-free,
+//   * the three coefficient products of a pair accumulated UNREDUCED (fs_mul_raw_acc: 81 MACs instead of a Montgomery
+//     product) into 18 columns per coefficient per lane; columns are added across the wave by shuffles and across the
+//     workgroup through LDS as plain integers, and lanes 0..2 turn the three totals into canonical field elements,
+//   * SC29_PPT pairs per lane instead of one or two, so that the per-workgroup epilogue is amortised.
+// The coefficients are algebraically the reference's (proof.cu:55-70,110-137,165-188) and every value written is canonical,
+// so the transcript is bit-identical.  Bounds (units of r; "n" = normalised): table entries and weights < 1; differences
+// x - y + 2r < 3; fs_mul(A, B) < 0.453 A B + 1.
+//   binary:    c0 = a0w (a0 - 1),  c1 = daw (2 a0 - 1),  c2 = daw da            with a0w = a0 w < 1.7, daw = da w < 3
+//   Hadamard:  c0 = a0w b0,  c2 = daw db,  c1 = (a0w + daw) b1 - c0 - c2
+//   inner:     c0 = a0 b0,   c2 = da db,   c1 = a1 b1 - c0 - c2
+static constexpr uint32_t SC29_PPT = 8;
+template <int MODE>
+__device__ __forceinline__ void k_sc_round29(uint32_t zk_nblk, const Fr* __restrict__ a, const Fr* __restrict__ b, Fr* __restrict__ a_out, Fr* __restrict__ b_out,
+                                                     const Fr* __restrict__ fold, ScLevels lv, const Fr* __restrict__ B, uint32_t in_size, uint32_t out_size,
+                                                     Fr* __restrict__ partial, const Fr* __restrict__ prev_partial, uint32_t prev_blocks, uint32_t prev_cols,
+                                                     Fr* __restrict__ prev_dst) {
+  __shared__ uint32_t quads[64 * 54];
+  __shared__ uint64_t tot[54];
+  __shared__ Fr Y[3], cres[9];
+  __shared__ Fr lds[12];
+  const Fs X = fs_unpack(fold[0]);
+  Fs ONE;
+#pragma unroll
+  for (int i = 0; i < 9; i++) ONE.v[i] = fs29::ONE(i);
+  uint32_t acc[3][18];
+#pragma unroll
+  for (int q = 0; q < 3; q++)
+#pragma unroll
+    for (int k = 0; k < 18; k++) acc[q][k] = 0;
+  // factored weights: see k_sc_round
+  uint32_t P = 0;
+  bool fact = false;
+  if (MODE != SC_IP) {
+    P = out_size / zk_nblk;
+    fact = lv.c[2] != 0xffu && P * zk_nblk == out_size && P >= blockDim.x && P % blockDim.x == 0 && lv.c[0] < 32 && P <= (1u << lv.c[0]) && ((1u << lv.c[0]) % P) == 0;
+  }
+  const uint32_t mask = (1u << lv.c[0]) - 1u;
+  const Fr zero = fr_zero();
+  // the multipliers of the epilogue, computed while the other lanes already sweep: 2^(232 j) mod r, times the
+  // workgroup's high weight when the weights factor (then the lanes weight by the low table only)
+  if (threadIdx.x < 3) {
+    Fr kj = fr_zero();
+    if (threadIdx.x == 0) kj.v[0] = 1u;
+    if (threadIdx.x == 1) kj.v[7] = 0x100u;
+    if (threadIdx.x == 2) {
+      constexpr uint32_t k2[8] = {0x528ebd8du, 0x6ebc8427u, 0x2e5747bau, 0x8a38d0a4u, 0xb00d5ba7u, 0xf98b22b4u, 0x247c4690u, 0x37402f0eu};  // 2^464 mod r
+#pragma unroll
+      for (int i = 0; i < 8; i++) kj.v[i] = k2[i];
+    }
+    if (fact) kj = fr_mul(kj, B[(blockIdx.x * P) >> lv.c[0]]);
+    Y[threadIdx.x] = kj;
+  }
+  auto sweep = [&](auto FACT) {
+    const uint32_t g_first = FACT.value ? blockIdx.x * P + threadIdx.x : blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t g_end = FACT.value ? (blockIdx.x + 1) * P : out_size;
+    const uint32_t g_step = FACT.value ? blockDim.x : zk_nblk * blockDim.x;
+    uint32_t it = 0;
+    for (uint32_t g = g_first; g < g_end; g += g_step) {
+      const uint64_t e0 = 2ull * g, e1 = e0 + 1;
+      const Fs A0 = fs_unpack(e0 < in_size ? a[e0] : zero), A1 = fs_unpack(e1 < in_size ? a[e1] : zero);
+      const Fs DA = fs_norm(fs_sub<2>(A1, A0));  // < 3
+      Fs W;
+      if (MODE != SC_IP) {
+        W = fs_unpack(lv.A[0][g & mask]);
+        if constexpr (!decltype(FACT)::value) W = fs_mul(W, fs_unpack(B[g >> lv.c[0]]));  // < 1.5
+      }
+      if (MODE == SC_BIN) {
+        const Fs A0W = fs_mul(A0, W), DAW = fs_mul(DA, W);                 // < 1.7, < 3
+        fs_mul_raw_acc(acc[0], A0W, fs_norm(fs_sub<2>(A0, ONE)));           // a0 - 1: < 3
+        fs_mul_raw_acc(acc[1], DAW, fs_norm(fs_sub<2>(fs_add(A0, A0), ONE)));  // 2 a0 - 1: < 4
+        fs_mul_raw_acc(acc[2], DAW, DA);
+      } else {
+        const Fs B0 = fs_unpack(e0 < in_size ? b[e0] : zero), B1 = fs_unpack(e1 < in_size ? b[e1] : zero);
+        const Fs DB = fs_norm(fs_sub<2>(B1, B0));
+        if (MODE == SC_HP) {
+          const Fs A0W = fs_mul(A0, W), DAW = fs_mul(DA, W);
+          fs_mul_raw_acc(acc[0], A0W, B0);
+          fs_mul_raw_acc(acc[1], fs_norm(fs_add(A0W, DAW)), B1);  // < 4.7
+          fs_mul_raw_acc(acc[2], DAW, DB);
+        } else {
+          fs_mul_raw_acc(acc[0], A0, B0);
+          fs_mul_raw_acc(acc[1], A1, B1);
+          fs_mul_raw_acc(acc[2], DA, DB);
+        }
+        b_out[g] = fs_to_fr(fs_norm(fs_add(B0, fs_mul(X, DB))));  // < 1 + 2.4
+      }
+      a_out[g] = fs_to_fr(fs_norm(fs_add(A0, fs_mul(X, DA))));
+      if ((++it & 3u) == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) fs_cols_norm(acc[q]);
+      }
+    }
+  };
+  if (fact) sweep(std::true_type{});
+  else sweep(std::false_type{});
+  // ---- the three column sets, lane -> workgroup, as plain integers: two DPP steps inside each quad (columns < 2^29 after
+  // the carry, so a quad's sum fits 32 bits), one lane per quad to LDS, 54 lanes add a column each over the 64 quads.
+#pragma unroll
+  for (int q = 0; q < 3; q++) fs_cols_norm(acc[q]);
+#pragma unroll
+  for (int q = 0; q < 3; q++)
+#pragma unroll
+    for (int k = 0; k < 18; k++) {
+      uint32_t v = acc[q][k];
+      v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+      v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+      acc[q][k] = v;
+    }
+  if ((threadIdx.x & 3u) == 0) {
+    uint32_t* dst = quads + (threadIdx.x >> 2) * 54;
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+      for (int k = 0; k < 18; k++) dst[q * 18 + k] = acc[q][k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 54) {
+    uint64_t t = 0;
+    for (uint32_t i = 0; i < blockDim.x / 4; i++) t += quads[i * 54 + threadIdx.x];
+    tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+  // nine lanes: (coefficient q, 232-bit chunk j) -> chunk * Y_j, Y_j = 2^(232 j) [* the workgroup's high weight] (fs_cols_to_fr)
+  if (threadIdx.x < 9) {
+    const uint32_t q = threadIdx.x / 3, j = threadIdx.x % 3;
+    uint32_t limb[24];
+    uint64_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 24; k++) {
+      uint64_t t = c + (k < 18 ? tot[q * 18 + k] : 0);
+      limb[k] = (uint32_t)t & fs29::MASK;
+      c = t >> 29;
+    }
+    Fs ch;
+#pragma unroll
+    for (int i = 0; i < 8; i++) ch.v[i] = j == 0 ? limb[i] : (j == 1 ? limb[8 + i] : limb[16 + i]);
+    ch.v[8] = 0;
+    uint32_t top;
+    cres[threadIdx.x] = fr_mul(fs_pack(ch, top), Y[j]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Fr t0 = fr_add(fr_add(cres[0], cres[1]), cres[2]);
+    Fr t1 = fr_add(fr_add(cres[3], cres[4]), cres[5]);
+    Fr t2 = fr_add(fr_add(cres[6], cres[7]), cres[8]);
+    if (MODE != SC_BIN) t1 = fr_sub(fr_sub(t1, t0), t2);
+    partial[(uint64_t)blockIdx.x * 3 + 0] = t0;
+    partial[(uint64_t)blockIdx.x * 3 + 1] = t1;
+    partial[(uint64_t)blockIdx.x * 3 + 2] = t2;
+  }
+  // workgroup 0 also closes the previous launch: its partials were completed by the kernel boundary
+  if (blockIdx.x == 0 && prev_blocks) {
+    __syncthreads();
+    for (uint32_t q = 0; q < prev_cols; q++) {
+      Fr t = fr_zero();
+      for (uint32_t i = threadIdx.x; i < prev_blocks; i += blockDim.x) t = fr_add(t, prev_partial[(uint64_t)i * prev_cols + q]);
+      t = block_sum_fr(t, lds);
+      if (threadIdx.x == 0) prev_dst[q] = t;
+    }
+  }
+}
+
 // Round 0 of a Hadamard sumcheck whose second operand is a 0/1 tensor given as one BYTE per element (zkReLU's sign tensor:
 // sign_packed): with b in {0, 1} four of the round's seven products are selects --
 //     c0 = b0 ? a0 w : 0,   (a0 w + da w) b1 = b1 ? a1 w : 0,   c2 = da w (b1 - b0) = 0 or +-da w,   b' = b0 + x (b1 - b0) in {0, x, 1 - x, 1}
@@ -333,6 +499,10 @@ __device__ __forceinline__ void k_sc_tail(uint32_t zk_nblk, const Fr* __restrict
   }
 }
 
+static bool sc29_enabled() {
+  static const bool off = getenv("ZKDL_SC_OLD") != nullptr;  // A/B switch: the 32-bit-limb rounds
+  return !off;
+}
 template <int MODE>
 static int run_sumcheck(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n, const Fr* fold_d, const Fr* weight_d, uint32_t k, Fr* proof_d, const uint8_t* b_bits = nullptr) {
   const bool two = (MODE != SC_BIN);
@@ -353,7 +523,10 @@ static int run_sumcheck(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n,
       return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: sumcheck tables");
     if (MODE != SC_IP) {
       // fixed split: every big round r (< nbig) needs c_r = s - 1 - r >= 0
+      // (with the 29-bit-limb rounds a workgroup covers 2^11 pairs: a wide low table keeps the high weight constant per workgroup)
       s = nbig;
+      static const bool wide_split = getenv("ZKDL_SC29_NARROW") == nullptr;  // A/B switch
+      if (sc29_enabled() && wide_split && k >= 6 && k - 6 > s) s = k - 6;
       if (s > k) s = k;
       if (!tabA.alloc(ctx, (size_t)1 << s) || !tabB.alloc(ctx, (size_t)1 << (k - s))) return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: sumcheck weights");
       uint32_t tot = (1u << s) + (1u << (k - s));
@@ -417,7 +590,17 @@ static int run_sumcheck(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n,
             prev_blocks, prev_cols, prev_dst)
     if (R == 3) ZK_SC_LAUNCH(3);
     else if (R == 2) ZK_SC_LAUNCH(2);
-    else ZK_SC_LAUNCH(1);
+    else if (!sc29_enabled() || getenv("ZKDL_SC29_OLDKERNEL")) ZK_SC_LAUNCH(1);
+    else {
+      // SC29_PPT pairs per lane, but at least 64 workgroups while each still gets a full 256 pairs (the factored weights
+      // need 2^(k-s) = 64 of them)
+      static const uint32_t ppt = [] { const char* e = getenv("ZKDL_SC29_PPT"); uint32_t v = e ? (uint32_t)strtoul(e, nullptr, 0) : SC29_PPT; return v ? v : 1u; }();
+      uint32_t g29 = stream_grid((osz + ppt - 1) / ppt, 256, SC_MAX_BLOCKS);
+      if (g29 < 64) g29 = osz / 256 >= 64 ? 64 : stream_grid(osz, 256, 64);
+      grid = g29;
+      ZK_LAUNCHB(ctx, tag, bytes, 256, (k_sc_round29<MODE>), dim3(grid), 0, a, b, ao, bo, fold_d + r, lv, (const Fr*)tabB.get(), sz, osz, part, prev_partial,
+                 prev_blocks, prev_cols, prev_dst);
+    }
 #undef ZK_SC_LAUNCH
     prev_partial = part;
     prev_blocks = grid;
