@@ -765,34 +765,113 @@ struct DeriveJob {
   const Fr* coef;
   uint32_t k, r0, lane_off;
 };
-// scalar * point with a signed 4-bit fixed window: k + sum_i 8 * 16^i has the nibbles (d_i + 8) with d_i in [-8, 7] and
-// k = sum_i d_i 16^i (no carries between digits: the same recoding as the bucket MSM's), so the lane keeps P .. 8P in a private
-// slice of `tab` (global, L2-resident) and runs 63 x (4 doublings + 1 addition): 252 doublings + ~71 additions instead of the 256 +
-// ~128 of the bitwise ladder -- this kernel is ONE wave's latency per lane, nothing else.
-__device__ __forceinline__ G1Q g1q_mul_w4(const G1Q& P, const Fr& k, G1Q* __restrict__ tab) {
-  // t = k + K, K = 0x888...8 (64 nibbles): 9 limbs
-  uint32_t t[9];
-  uint32_t carry = 0;
+// ---- scalar * point for the derived round commitments: ONE lane's latency per product, so the chain is what counts.
+//  * GLV split.  G1 has the endomorphism phi(x, y) = (beta x, y) = lambda * (x, y) with lambda^2 + lambda + 1 = 0 mod r and
+//    lambda = z^2 - 1 only 128 bits long (z the curve parameter), so k = k1 + k2 lambda with k2 = floor(k / lambda) and
+//    k1 = k mod lambda both < 2^128 and  k P = k1 P + k2 phi(P):  two lanes run a 128-bit product each (of P and of phi(P), which
+//    costs one field product) and the even lane adds the two halves -- half the doublings on the critical path.
+//  * Signed 4-bit fixed window: s + sum_i 8 * 16^i has the nibbles (d_i + 8) with d_i in [-8, 7] and s = sum_i d_i 16^i (no carries
+//    between digits: the same recoding as the bucket MSM's), so the lane keeps P .. 8P in a private slice of `tab` (global,
+//    L2-resident) and runs 32 x (4 doublings + 1 addition).
+//  * The group law runs on the 28-bit-limb field (g1q.hpp).
+// k = k1 + k2 * lambda, 0 <= k1 < lambda, k2 <= lambda + 1 (k < r = lambda^2 + lambda + 1)
+__device__ __forceinline__ void glv_split(const Fr& k, uint32_t (&k1)[4], uint32_t (&k2)[4]) {
+  constexpr uint32_t LAM[4] = {0xffffffffu, 0x00000000u, 0x0001a402u, 0xac45a401u};               // lambda
+  constexpr uint32_t MU[5] = {0xf6cfee30u, 0x63f6e522u, 0xe01faaddu, 0x7c6becf1u, 0x1u};          // floor(2^256 / lambda)
+  // q = (k * mu) >> 256: floor(k / lambda) or one less
+  uint32_t prod[13];
+#pragma unroll
+  for (int i = 0; i < 13; i++) prod[i] = 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      uint64_t t = (uint64_t)k.v[i] * MU[j] + prod[i + j] + c;
+      prod[i + j] = (uint32_t)t;
+      c = t >> 32;
+    }
+    prod[i + 5] = (uint32_t)c;
+  }
+  uint32_t q[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) q[i] = prod[8 + i];
+  // rem = k - q * lambda (< 2 lambda < 2^129): five limbs are enough
+  uint32_t ql[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) ql[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (i + j < 5) {
+        uint64_t t = (uint64_t)q[i] * LAM[j] + ql[i + j] + c;
+        ql[i + j] = (uint32_t)t;
+        c = t >> 32;
+      }
+    }
+    if (i == 0) ql[4] = (uint32_t)c;  // the only row whose carry still lands inside the five limbs
+  }
+  uint32_t rem[5], bw = 0;
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    uint32_t bo;
+    rem[i] = __builtin_subc(k.v[i], ql[i], bw, &bo);
+    bw = bo;
+  }
+#pragma unroll 1
+  for (int pass = 0; pass < 2; pass++) {  // at most one correction is ever needed (the estimate is off by <= 1); two are harmless
+    uint32_t d[5], b2 = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      uint32_t bo;
+      d[i] = __builtin_subc(rem[i], i < 4 ? LAM[i] : 0u, b2, &bo);
+      b2 = bo;
+    }
+    if (b2 == 0) {  // rem >= lambda
+#pragma unroll
+      for (int i = 0; i < 5; i++) rem[i] = d[i];
+      uint32_t c = 1;
+#pragma unroll
+      for (int i = 0; i < 5; i++) {
+        uint32_t co;
+        q[i] = __builtin_addc(q[i], 0u, c, &co);
+        c = co;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    k1[i] = rem[i];
+    k2[i] = q[i];
+  }
+}
+__device__ __forceinline__ G1Q g1q_mul128_w4(const G1Q& P, const uint32_t (&k)[4], G1Q* __restrict__ tab) {
+  // t = k + K, K = 0x888...8 (32 nibbles): 4 limbs + a carry digit
+  uint32_t t[5];
+  uint32_t carry = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
     uint32_t co;
-    t[i] = __builtin_addc(k.v[i], 0x88888888u, carry, &co);
+    t[i] = __builtin_addc(k[i], 0x88888888u, carry, &co);
     carry = co;
   }
-  t[8] = carry;  // digit 64: 0 or 1 (its "+8" was not added: plain digit)
+  t[4] = carry;  // digit 32: 0 or 1 (its "+8" was not added: plain digit)
   tab[0] = P;
   G1Q acc = g1q_double(P);
   tab[1] = acc;
+#pragma unroll 1
   for (int i = 2; i < 8; i++) {
     acc = g1q_add(acc, P);
     tab[i] = acc;
   }
-  acc = t[8] ? P : g1q_zero();
+  acc = t[4] ? P : g1q_zero();
 #pragma unroll 1
-  for (int w = 7; w >= 0; w--) {
+  for (int w = 3; w >= 0; w--) {
     uint32_t limb = t[0];
 #pragma unroll
-    for (int i = 1; i < 8; i++) limb = (w == i) ? t[i] : limb;
+    for (int i = 1; i < 4; i++) limb = (w == i) ? t[i] : limb;
 #pragma unroll 1
     for (int nb = 7; nb >= 0; nb--) {
 #pragma unroll 1
@@ -807,19 +886,44 @@ __device__ __forceinline__ G1Q g1q_mul_w4(const G1Q& P, const Fr& k, G1Q* __rest
   }
   return acc;
 }
-// one lane per (job, r, s): tmp[lane] = coef * point
+// two lanes per (job, r, s): the halves k1 * P and k2 * phi(P) of coef * point; tmp[pair] = their sum
 __global__ void __launch_bounds__(64) k_derive_mul(const DeriveJob* __restrict__ jobs, uint32_t nj, uint32_t total, G1Q* __restrict__ tmp, G1Q* __restrict__ tabs) {
   const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-  if (lane >= total) return;
-  uint32_t q = 0;
-  while (q + 1 < nj && jobs[q + 1].lane_off <= lane) q++;
-  const DeriveJob job = jobs[q];
-  const uint32_t idx = lane - job.lane_off + job.r0;
-  uint32_t r = 0;
-  while ((r + 1) * (r + 1) <= idx) r++;
-  const uint32_t s = idx - r * r;
-  const G1J P = s == 0 ? *job.base : job.proof[3u * ((s - 1) >> 1) + ((s & 1u) ? 1u : 2u)];
-  tmp[lane] = g1q_mul_w4(g1q_from_jacobian(P), job.coef[idx], tabs + (size_t)lane * 8);
+  const uint32_t pair = lane >> 1, half = lane & 1u;
+  const bool live = pair < total;
+  G1Q acc = g1q_zero();
+  if (live) {
+    uint32_t q = 0;
+    while (q + 1 < nj && jobs[q + 1].lane_off <= pair) q++;
+    const DeriveJob job = jobs[q];
+    const uint32_t idx = pair - job.lane_off + job.r0;
+    uint32_t r = 0;
+    while ((r + 1) * (r + 1) <= idx) r++;
+    const uint32_t s = idx - r * r;
+    const G1J P = s == 0 ? *job.base : job.proof[3u * ((s - 1) >> 1) + ((s & 1u) ? 1u : 2u)];
+    uint32_t k1[4], k2[4];
+    glv_split(job.coef[idx], k1, k2);
+    G1Q Q = g1q_from_jacobian(P);
+    if (half) {
+      constexpr uint32_t beta[14] = {37886809u, 200165479u, 30609410u, 74842500u, 80498822u, 209116160u, 179210523u,
+                                     180816594u, 266565572u, 239503032u, 99423592u, 150315392u, 2841631u, 53668u};  // beta * 2^392 mod p
+      Fq bq;
+#pragma unroll
+      for (int i = 0; i < 14; i++) bq.v[i] = beta[i];
+      Q.x = fq_mul(Q.x, bq);  // phi(X, Y, Z) = (beta X, Y, Z)
+#pragma unroll
+      for (int i = 0; i < 4; i++) k1[i] = k2[i];
+    }
+    acc = g1q_mul128_w4(Q, k1, tabs + (size_t)lane * 8);
+  }
+  G1Q other;
+#pragma unroll
+  for (int i = 0; i < 14; i++) {
+    other.x.v[i] = __shfl_xor(acc.x.v[i], 1, 64);
+    other.y.v[i] = __shfl_xor(acc.y.v[i], 1, 64);
+    other.z.v[i] = __shfl_xor(acc.z.v[i], 1, 64);
+  }
+  if (live && !half) tmp[pair] = g1q_add(acc, other);
 }
 // one lane per (job, r): proof[3r] = sum of its 2r + 1 products
 __global__ void __launch_bounds__(64) k_derive_sum(const DeriveJob* __restrict__ jobs, uint32_t nj, uint32_t nseg, const uint32_t* __restrict__ seg_job, const G1Q* __restrict__ tmp) {
@@ -855,7 +959,7 @@ int msm_run_derives(zk_ctx* ctx, const std::vector<DeriveJobHost>& derives) {
   ZK_ALLOC(ctx, djobs, DeriveJob, nj);
   ZK_ALLOC(ctx, dseg, uint32_t, seg.size());
   ZK_ALLOC(ctx, tmp, G1Q, total);
-  ZK_ALLOC(ctx, tabs, G1Q, (size_t)total * 8);
+  ZK_ALLOC(ctx, tabs, G1Q, (size_t)total * 16);
   {
     void* st = ctx->stage_put(jobs.data(), jobs.size() * sizeof(DeriveJob));
     if (!st) return ctx->fail(ZK_ERR_ALLOC, "pinned staging exhausted");
@@ -864,7 +968,7 @@ int msm_run_derives(zk_ctx* ctx, const std::vector<DeriveJobHost>& derives) {
     if (!st) return ctx->fail(ZK_ERR_ALLOC, "pinned staging exhausted");
     ZK_TRY(dev_copy(ctx, dseg.get(), st, (seg.size() * 4 + 15) & ~(size_t)15));
   }
-  ZK_LAUNCH(ctx, "msm_derive", 320ull * total, k_derive_mul, dim3((total + 63) / 64), dim3(64), 0, (const DeriveJob*)djobs.get(), nj, total, tmp.get(), tabs.get());
+  ZK_LAUNCH(ctx, "msm_derive", 320ull * total, k_derive_mul, dim3((2 * total + 63) / 64), dim3(64), 0, (const DeriveJob*)djobs.get(), nj, total, tmp.get(), tabs.get());
   ZK_LAUNCH(ctx, "msm_derive", 144ull * total, k_derive_sum, dim3((nseg + 63) / 64), dim3(64), 0, (const DeriveJob*)djobs.get(), nj, nseg, (const uint32_t*)dseg.get(), (const G1Q*)tmp.get());
   return ZK_OK;
 }
