@@ -348,7 +348,7 @@ def main():
     ap.add_argument("--prof-steps", type=int, default=2, help="proofs per event-profiled pass after the timed region (ZKDL_PROF_TRACE=<file> writes their per-launch timeline)")
     ap.add_argument("--pair", type=int, default=1, choices=[1, 2], help="proofs submitted together (zk_transcript_seal_pair): 2 = the Fr phases of two consecutive "
                     "proofs share their launches; every proof is still its own batch-256 proof with its own transcript and digest row")
-    ap.add_argument("--inflight", type=int, default=3, help="transcripts rotated by the pipelined loop (proofs whose G1 phase may still be running)")
+    ap.add_argument("--inflight", type=int, default=4, help="transcripts rotated by the pipelined loop (proofs whose G1 phase may still be running)")
     ap.add_argument("--no-derive", action="store_true", help="run every round commitment T_r of the openings as an MSM (library default) instead of deriving T_1.. from the "
                     "folding relation behind the MSM batch (the throughput configuration: -31 %% msm_accum work, a ~6 ms longer G1 phase per proof)")
     ap.add_argument("--serial", action="store_true", help="no worker streams at all: every launch runs alone (the schedule the roofline durations are measured under)")

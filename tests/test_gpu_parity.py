@@ -512,6 +512,62 @@ def test_sealed_transcripts_pipeline_proofs_without_changing_them(zk, oracle):
     assert eq(fr, want[0][0])
 
 
+def test_paired_sealing_zips_two_proofs_without_changing_them(zk, oracle):
+    """zk_transcript_seal_pair: two proofs recorded on two transcripts, their Fr chains merged into one set of batched launches, each
+    G1 phase on its own stream.  Pure scheduling: both transcripts and both device digests equal the ones of proving each proof alone;
+    pairs can follow each other back to back, with derived round commitments on or off, and degrade to two plain seals without lanes."""
+    import numpy as np
+    from mlp_util import enqueue_proof, setup_mlp_gpu, synth_mlp
+    from zkdl_amd.capi import MSM_PIPPENGER, Transcript
+    from zkdl_amd.dist import lanes_to_fr
+    zk.set_msm_mode(MSM_PIPPENGER)
+    model = synth_mlp(oracle, [16, 32, 24, 8], 4, seed=35)
+    st = setup_mlp_gpu(zk, model)
+    chals = [model["chal"]] + [model["draw_chal"]() for _ in range(5)]
+    want = []
+    tr0 = Transcript(zk)
+    for ch in chals:
+        tr0.reset()
+        enqueue_proof(st, ch, tr0)
+        fr, _ = tr0.read()
+        aff, inf = tr0.read_affine()
+        want.append((fr, aff, inf, tr0.digest()))
+    trs = [Transcript(zk) for _ in range(4)]
+    lanes = [zk.empty(2, 8) for _ in range(4)]
+
+    def check(slot, i):
+        fr, _ = trs[slot].read()
+        aff, inf = trs[slot].read_affine()
+        assert eq(fr, want[i][0]) and eq(aff, want[i][1]) and eq(inf, want[i][2])
+        l64 = lanes[slot].download().reshape(-1).view(np.uint64)
+        assert lanes_to_fr([int(x) for x in l64]) == int.from_bytes(np.ascontiguousarray(want[i][3]).tobytes(), "little")
+
+    for derive in (0, 1):
+        zk.set_flag("derive_rounds", derive)
+        for base in (0, 2):                      # two pairs enqueued back to back before anything is read
+            for j in (0, 1):
+                trs[base + j].reset()
+                enqueue_proof(st, chals[base + j], trs[base + j])
+            trs[base].seal_pair(trs[base + 1], lanes[base].ptr, lanes[base + 1].ptr)
+        for slot in range(4):
+            check(slot, slot)
+    zk.set_flag("derive_rounds", 0)
+    # an empty partner, and no worker lanes: same values
+    trs[0].reset()
+    trs[1].reset()
+    enqueue_proof(st, chals[4], trs[0])
+    trs[0].seal_pair(trs[1], lanes[0].ptr, None)
+    check(0, 4)
+    zk.set_flag("lanes", 0)
+    for j in (0, 1):
+        trs[j].reset()
+        enqueue_proof(st, chals[4 + j], trs[j])
+    trs[0].seal_pair(trs[1], lanes[0].ptr, lanes[1].ptr)
+    zk.set_flag("lanes", 1)
+    check(0, 4)
+    check(1, 5)
+
+
 def test_recorded_batched_layers_equal_immediate_execution(zk, oracle):
     """zk_fc_prove / zk_relu_prove only RECORD their launches; the flush zips the same kernel of different
     layers into one launch (blockIdx.z = job) and spreads independent pieces over streams.  Pure scheduling:

@@ -73,27 +73,27 @@ ZK_HD constexpr SubConst sub_const(uint32_t K, uint32_t nsub) {
 typedef uint32_t zk_q4 __attribute__((ext_vector_type(4)));
 typedef uint32_t zk_q2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ Fq fq_zero() {
+ZK_HD Fq fq_zero() {
   Fq r;
 #pragma unroll
   for (int i = 0; i < 14; i++) r.v[i] = 0;
   return r;
 }
-__device__ __forceinline__ Fq fq_one() {
+ZK_HD Fq fq_one() {
   Fq r;
 #pragma unroll
   for (int i = 0; i < 14; i++) r.v[i] = fq28::ONE(i);
   return r;
 }
 // every limb zero (the explicit infinity marker; NOT a test for "is a multiple of p")
-__device__ __forceinline__ bool fq_all_zero(const Fq& a) {
+ZK_HD bool fq_all_zero(const Fq& a) {
   uint32_t acc = 0;
 #pragma unroll
   for (int i = 0; i < 14; i++) acc |= a.v[i];
   return acc == 0;
 }
 // a normalised, < 2p:  a == 0 (mod p)  <=>  a is 0 or p
-__device__ __forceinline__ bool fq_is_zero_mod_p(const Fq& a) {
+ZK_HD bool fq_is_zero_mod_p(const Fq& a) {
   uint32_t z = 0, e = 0;
 #pragma unroll
   for (int i = 0; i < 14; i++) {
@@ -105,7 +105,7 @@ __device__ __forceinline__ bool fq_is_zero_mod_p(const Fq& a) {
 
 // ---- Montgomery product, product scanning with a 64-bit column accumulator and no carries.
 // returns (a*b + m*p) / 2^392, normalised, < a*b/2^392 + p.
-__device__ __forceinline__ Fq fq_mul_inl(const Fq& a, const Fq& b) {
+ZK_HD Fq fq_mul_inl(const Fq& a, const Fq& b) {
   constexpr int N = 14;
   uint32_t m[N];
   Fq t;
@@ -133,7 +133,7 @@ __device__ __forceinline__ Fq fq_mul_inl(const Fq& a, const Fq& b) {
   return t;
 }
 // square: the cross products once, against the doubled operand.  Needs 7 * 2 * max_limb(a)^2 < 2^63.
-__device__ __forceinline__ Fq fq_sqr_inl(const Fq& a) {
+ZK_HD Fq fq_sqr_inl(const Fq& a) {
   constexpr int N = 14;
   uint32_t m[N], d[N];
 #pragma unroll
@@ -166,7 +166,7 @@ __device__ __forceinline__ Fq fq_sqr_inl(const Fq& a) {
 }
 // Real device calls (a mixed addition holds ten of them); operands travel in VGPRs as vector arguments, see
 // field.hpp:fp_mul_regs.
-static __device__ __attribute__((noinline)) Fq fq_mul_regs(zk_q4 a0, zk_q4 a1, zk_q4 a2, zk_q2 a3, zk_q4 b0, zk_q4 b1, zk_q4 b2, zk_q2 b3) {
+static ZK_HD_CALL Fq fq_mul_regs(zk_q4 a0, zk_q4 a1, zk_q4 a2, zk_q2 a3, zk_q4 b0, zk_q4 b1, zk_q4 b2, zk_q2 b3) {
   Fq a, b;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -177,7 +177,7 @@ static __device__ __attribute__((noinline)) Fq fq_mul_regs(zk_q4 a0, zk_q4 a1, z
   b.v[12] = b3[0]; b.v[13] = b3[1];
   return fq_mul_inl(a, b);
 }
-static __device__ __attribute__((noinline)) Fq fq_sqr_regs(zk_q4 a0, zk_q4 a1, zk_q4 a2, zk_q2 a3) {
+static ZK_HD_CALL Fq fq_sqr_regs(zk_q4 a0, zk_q4 a1, zk_q4 a2, zk_q2 a3) {
   Fq a;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -186,20 +186,20 @@ static __device__ __attribute__((noinline)) Fq fq_sqr_regs(zk_q4 a0, zk_q4 a1, z
   a.v[12] = a3[0]; a.v[13] = a3[1];
   return fq_sqr_inl(a);
 }
-__device__ __forceinline__ Fq fq_mul(const Fq& a, const Fq& b) {
+ZK_HD Fq fq_mul(const Fq& a, const Fq& b) {
   zk_q4 a0 = {a.v[0], a.v[1], a.v[2], a.v[3]}, a1 = {a.v[4], a.v[5], a.v[6], a.v[7]}, a2 = {a.v[8], a.v[9], a.v[10], a.v[11]};
   zk_q4 b0 = {b.v[0], b.v[1], b.v[2], b.v[3]}, b1 = {b.v[4], b.v[5], b.v[6], b.v[7]}, b2 = {b.v[8], b.v[9], b.v[10], b.v[11]};
   zk_q2 a3 = {a.v[12], a.v[13]}, b3 = {b.v[12], b.v[13]};
   return fq_mul_regs(a0, a1, a2, a3, b0, b1, b2, b3);
 }
-__device__ __forceinline__ Fq fq_sqr(const Fq& a) {
+ZK_HD Fq fq_sqr(const Fq& a) {
   zk_q4 a0 = {a.v[0], a.v[1], a.v[2], a.v[3]}, a1 = {a.v[4], a.v[5], a.v[6], a.v[7]}, a2 = {a.v[8], a.v[9], a.v[10], a.v[11]};
   zk_q2 a3 = {a.v[12], a.v[13]};
   return fq_sqr_regs(a0, a1, a2, a3);
 }
 
 // limb-wise sum: limbs and value add up
-__device__ __forceinline__ Fq fq_add(const Fq& a, const Fq& b) {
+ZK_HD Fq fq_add(const Fq& a, const Fq& b) {
   Fq r;
 #pragma unroll
   for (int i = 0; i < 14; i++) r.v[i] = a.v[i] + b.v[i];
@@ -207,7 +207,7 @@ __device__ __forceinline__ Fq fq_add(const Fq& a, const Fq& b) {
 }
 // a + K p - b,  b normalised with value(b) <= K p / 2:  value < value(a) + K p,  limbs < max_limb(a) + 2^29
 template <uint32_t K>
-__device__ __forceinline__ Fq fq_sub(const Fq& a, const Fq& b) {
+ZK_HD Fq fq_sub(const Fq& a, const Fq& b) {
   constexpr fq28::SubConst C = fq28::sub_const(K, 1);
   Fq r;
 #pragma unroll
@@ -216,7 +216,7 @@ __device__ __forceinline__ Fq fq_sub(const Fq& a, const Fq& b) {
 }
 // a + K p - b - c - c  (b, c normalised, value(b) + 2 value(c) <= K p / 2): limbs < max_limb(a) + 2^30
 template <uint32_t K>
-__device__ __forceinline__ Fq fq_sub3(const Fq& a, const Fq& b, const Fq& c) {
+ZK_HD Fq fq_sub3(const Fq& a, const Fq& b, const Fq& c) {
   constexpr fq28::SubConst C = fq28::sub_const(K, 3);
   Fq r;
 #pragma unroll
@@ -225,7 +225,7 @@ __device__ __forceinline__ Fq fq_sub3(const Fq& a, const Fq& b, const Fq& c) {
 }
 // a + K p - b - c  (b, c normalised, value(b) + value(c) < K p)
 template <uint32_t K>
-__device__ __forceinline__ Fq fq_sub2(const Fq& a, const Fq& b, const Fq& c) {
+ZK_HD Fq fq_sub2(const Fq& a, const Fq& b, const Fq& c) {
   constexpr fq28::SubConst C = fq28::sub_const(K, 2);
   Fq r;
 #pragma unroll
@@ -234,7 +234,7 @@ __device__ __forceinline__ Fq fq_sub2(const Fq& a, const Fq& b, const Fq& c) {
 }
 // a + K p - 8 c  (c normalised, 8 value(c) < K p): limbs < max_limb(a) + 2^31 + 2^28
 template <uint32_t K>
-__device__ __forceinline__ Fq fq_sub8(const Fq& a, const Fq& c) {
+ZK_HD Fq fq_sub8(const Fq& a, const Fq& c) {
   constexpr fq28::SubConst C = fq28::sub_const(K, 8);
   Fq r;
 #pragma unroll
@@ -242,7 +242,7 @@ __device__ __forceinline__ Fq fq_sub8(const Fq& a, const Fq& c) {
   return r;
 }
 // carry the limbs back under 2^28 (value unchanged)
-__device__ __forceinline__ Fq fq_norm(const Fq& a) {
+ZK_HD Fq fq_norm(const Fq& a) {
   Fq r;
   uint32_t c = 0;
 #pragma unroll
@@ -256,7 +256,7 @@ __device__ __forceinline__ Fq fq_norm(const Fq& a) {
 }
 
 // 12 x 32 bits (any value < 2^384) -> 14 x 28 bits, same integer
-__device__ __forceinline__ Fq fq_unpack(const Fp& a) {
+ZK_HD Fq fq_unpack(const Fp& a) {
   Fq r;
 #pragma unroll
   for (int i = 0; i < 14; i++) {
@@ -271,7 +271,7 @@ __device__ __forceinline__ Fq fq_unpack(const Fp& a) {
   return r;
 }
 // normalised, value < 2^384 -> 12 x 32 bits
-__device__ __forceinline__ Fp fq_pack(const Fq& a) {
+ZK_HD Fp fq_pack(const Fq& a) {
   Fp r;
 #pragma unroll
   for (int j = 0; j < 12; j++) {
@@ -284,7 +284,7 @@ __device__ __forceinline__ Fp fq_pack(const Fq& a) {
   return r;
 }
 // n-form, any bounded value -> canonical o-form (x 2^384 mod p, fully reduced): the way out of the pipeline
-__device__ __forceinline__ Fp fq_to_fp(const Fq& a) {
+ZK_HD Fp fq_to_fp(const Fq& a) {
   Fq c;
 #pragma unroll
   for (int i = 0; i < 14; i++) c.v[i] = fq28::C384(i);
@@ -292,7 +292,7 @@ __device__ __forceinline__ Fp fq_to_fp(const Fq& a) {
 }
 
 // canonical o-form (x 2^384 mod p, 12 x 32 bits) -> n-form: the way into the pipeline for values that do not come from a window table
-__device__ __forceinline__ Fq fq_from_fp(const Fp& a) {
+ZK_HD Fq fq_from_fp(const Fp& a) {
   constexpr uint32_t c400[14] = {135160473u, 55574580u, 246491222u, 233514649u, 211322480u, 82798231u, 118064104u,
                                  172912617u, 65577043u, 248456990u, 203477795u, 116089733u, 75436678u, 87770u};  // 2^400 mod p
   Fq c;
@@ -301,7 +301,7 @@ __device__ __forceinline__ Fq fq_from_fp(const Fp& a) {
   return fq_mul(fq_unpack(a), c);  // a 2^400 / 2^392 = a 2^8
 }
 // a^(p-2), a normalised and < 2^5 p (Fermat inverse; backs the affine-canonical form, see field.hpp:fp_inv)
-__device__ __forceinline__ Fq fq_inv(const Fq& a) {
+ZK_HD Fq fq_inv(const Fq& a) {
   Fq acc = fq_one();
 #pragma unroll 1
   for (int i = 12 * 32 - 1; i >= 0; i--) {

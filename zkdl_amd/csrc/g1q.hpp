@@ -17,15 +17,15 @@ namespace zk {
 struct alignas(8) G1Q {
   Fq x, y, z;
 };
-__device__ __forceinline__ G1Q g1q_zero() {
+ZK_HD G1Q g1q_zero() {
   G1Q r;
   r.x = fq_zero();
   r.y = fq_one();
   r.z = fq_zero();
   return r;
 }
-__device__ __forceinline__ bool g1q_is_zero(const G1Q& a) { return fq_all_zero(a.z); }
-__device__ __forceinline__ G1Q g1q_from_jacobian(const G1J& a) {
+ZK_HD bool g1q_is_zero(const G1Q& a) { return fq_all_zero(a.z); }
+ZK_HD G1Q g1q_from_jacobian(const G1J& a) {
   if (l_is_zero(a.z)) return g1q_zero();
   G1Q r;
   r.x = fq_from_fp(a.x);
@@ -33,7 +33,7 @@ __device__ __forceinline__ G1Q g1q_from_jacobian(const G1J& a) {
   r.z = fq_from_fp(a.z);
   return r;
 }
-__device__ __forceinline__ G1J g1q_to_jacobian(const G1Q& a) {
+ZK_HD G1J g1q_to_jacobian(const G1Q& a) {
   if (g1q_is_zero(a)) return g1_zero();
   G1J r;
   r.x = fq_to_fp(a.x);
@@ -41,7 +41,7 @@ __device__ __forceinline__ G1J g1q_to_jacobian(const G1Q& a) {
   r.z = fq_to_fp(a.z);
   return r;
 }
-__device__ __forceinline__ G1Q g1q_double(const G1Q& q) {
+ZK_HD G1Q g1q_double(const G1Q& q) {
   if (g1q_is_zero(q)) return q;
   const Fq a = fq_sqr(q.x), b = fq_sqr(q.y), c = fq_sqr(b);
   const Fq d0 = fq_norm(fq_sub2<5>(fq_sqr(fq_add(q.x, b)), a, c));  // (x + b)^2 - a - c: < 7
@@ -54,7 +54,7 @@ __device__ __forceinline__ G1Q g1q_double(const G1Q& q) {
   o.z = fq_norm(fq_add(yz, yz));                                     // < 4
   return o;
 }
-__device__ __forceinline__ G1Q g1q_add(const G1Q& a, const G1Q& b) {
+ZK_HD G1Q g1q_add(const G1Q& a, const G1Q& b) {
   if (g1q_is_zero(a)) return b;
   if (g1q_is_zero(b)) return a;
   const Fq z1z1 = fq_sqr(a.z), z2z2 = fq_sqr(b.z);
@@ -73,13 +73,13 @@ __device__ __forceinline__ G1Q g1q_add(const G1Q& a, const G1Q& b) {
   o.z = fq_mul(fq_sub2<5>(fq_sqr(fq_add(a.z, b.z)), z1z1, z2z2), h);  // ((z1 + z2)^2 - z1z1 - z2z2) h: < 2
   return o;
 }
-__device__ __forceinline__ G1Q g1q_neg(const G1Q& a) {
+ZK_HD G1Q g1q_neg(const G1Q& a) {
   G1Q r = a;
   r.y = fq_norm(fq_sub<20>(fq_zero(), a.y));  // < 20
   return r;
 }
 // (x, y, 1) canonical, fully reduced, in the library's form; infinity as {0, ONE, 0}
-__device__ __forceinline__ G1J g1q_canonical(const G1Q& a) {
+ZK_HD G1J g1q_canonical(const G1Q& a) {
   if (g1q_is_zero(a)) return g1_zero();
   const Fq zi = fq_inv(a.z), zi2 = fq_sqr(zi);
   G1J r;
