@@ -579,7 +579,7 @@ def main():
         slots = prof["msm_accum"]["bytes"] / 100.0 / max(prof["msm_accum"]["launches"], 1)
         items = min(slots, real_pairs * 26.0) if args.msm == "pippenger" and not args.msm_window else slots
         macs_per_launch["msm_accum"] = items * 10 * FP_MACS   # 8M + 2S per XYZZ mixed add
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_r02.json")
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_r02c.json")
     pmc_all = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
     cands = [k for k in kernels if k in macs_per_launch] or list(kernels)[:1]
     dom = max(cands, key=lambda k: kernels[k]["ms_per_step"])
@@ -604,7 +604,7 @@ def main():
                         "traffic_bytes_per_launch": traffic},
                 "pmc": {k: pmc_hit[k] for k in pmc_hit if k not in ("fetch_kb_per_launch", "write_kb_per_launch")} if pmc_hit else None,
                 "note": "wide-integer modular arithmetic: no MFMA mapping; HBM traffic (PMC) equals the algorithmic bytes, the SIMDs are instruction-issue bound "
-                        "(profiles/pmc_r02.json: VALU busy); peak = measured issue rate of the MAC instruction, so frac is the share of issue slots doing algorithmic MACs",
+                        "(profiles/pmc_r02c.json: VALU busy); peak = measured issue rate of the MAC instruction, so frac is the share of issue slots doing algorithmic MACs",
                 "other_kernels_TMACps": {k: macs_per_launch[k] / (prof[k]["ms"] / max(prof[k]["launches"], 1)) / 1e9 for k in macs_per_launch if k != dom and prof[k]["ms"] > 0}}
 
     out = {"metric": "proving ms/example (batch 256) on 18M-param MLP", "value": value, "unit": "ms/example", "n_gpus": world, "steps": args.steps,

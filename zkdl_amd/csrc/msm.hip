@@ -925,17 +925,34 @@ __global__ void __launch_bounds__(64) k_derive_mul(const DeriveJob* __restrict__
   }
   if (live && !half) tmp[pair] = g1q_add(acc, other);
 }
-// one lane per (job, r): proof[3r] = sum of its 2r + 1 products
+// four lanes per (job, r): proof[3r] = sum of its 2r + 1 products, each lane adding every fourth one, then two butterfly steps
+// (a single lane would chain up to 41 additions behind the 128-bit products)
 __global__ void __launch_bounds__(64) k_derive_sum(const DeriveJob* __restrict__ jobs, uint32_t nj, uint32_t nseg, const uint32_t* __restrict__ seg_job, const G1Q* __restrict__ tmp) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nseg) return;
-  const uint32_t q = seg_job[2 * t], r = seg_job[2 * t + 1];
-  const DeriveJob job = jobs[q];
-  const G1Q* p = tmp + job.lane_off + (r * r - job.r0);
-  G1Q acc = p[0];
+  const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t t = lane >> 2, sub = lane & 3u;
+  const bool live = t < nseg;
+  G1Q acc = g1q_zero();
+  uint32_t q = 0, r = 0;
+  if (live) {
+    q = seg_job[2 * t];
+    r = seg_job[2 * t + 1];
+    const DeriveJob job = jobs[q];
+    const G1Q* p = tmp + job.lane_off + (r * r - job.r0);
 #pragma unroll 1
-  for (uint32_t s = 1; s < 2 * r + 1; s++) acc = g1q_add(acc, p[s]);
-  job.proof[3 * r] = g1q_to_jacobian(acc);
+    for (uint32_t s = sub; s < 2 * r + 1; s += 4) acc = g1q_add(acc, p[s]);
+  }
+#pragma unroll 1
+  for (int m = 1; m < 4; m <<= 1) {
+    G1Q other;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+      other.x.v[i] = __shfl_xor(acc.x.v[i], m, 64);
+      other.y.v[i] = __shfl_xor(acc.y.v[i], m, 64);
+      other.z.v[i] = __shfl_xor(acc.z.v[i], m, 64);
+    }
+    acc = g1q_add(acc, other);
+  }
+  if (live && sub == 0) jobs[q].proof[3 * r] = g1q_to_jacobian(acc);
 }
 int msm_run_derives(zk_ctx* ctx, const std::vector<DeriveJobHost>& derives) {
   if (derives.empty()) return ZK_OK;
@@ -969,7 +986,7 @@ int msm_run_derives(zk_ctx* ctx, const std::vector<DeriveJobHost>& derives) {
     ZK_TRY(dev_copy(ctx, dseg.get(), st, (seg.size() * 4 + 15) & ~(size_t)15));
   }
   ZK_LAUNCH(ctx, "msm_derive", 320ull * total, k_derive_mul, dim3((2 * total + 63) / 64), dim3(64), 0, (const DeriveJob*)djobs.get(), nj, total, tmp.get(), tabs.get());
-  ZK_LAUNCH(ctx, "msm_derive", 144ull * total, k_derive_sum, dim3((nseg + 63) / 64), dim3(64), 0, (const DeriveJob*)djobs.get(), nj, nseg, (const uint32_t*)dseg.get(), (const G1Q*)tmp.get());
+  ZK_LAUNCH(ctx, "msm_derive", 144ull * total, k_derive_sum, dim3((4 * nseg + 63) / 64), dim3(64), 0, (const DeriveJob*)djobs.get(), nj, nseg, (const uint32_t*)dseg.get(), (const G1Q*)tmp.get());
   return ZK_OK;
 }
 
