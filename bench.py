@@ -346,6 +346,8 @@ def main():
     ap.add_argument("--spinup-ms", type=float, default=400.0, help="untimed proofs before the W warm-up steps until this much wall time has passed: the first process on a "
                     "fresh box otherwise runs its first ~100 ms 12 %% slow (GPU power state); 0 disables")
     ap.add_argument("--prof-steps", type=int, default=2, help="proofs per event-profiled pass after the timed region (ZKDL_PROF_TRACE=<file> writes their per-launch timeline)")
+    ap.add_argument("--drain", type=int, default=1, help="the last N proofs of a run take the short G1 form (every round commitment an MSM instead of derived): "
+                    "they have no later proofs to hide the longer derived form under")
     ap.add_argument("--pair", type=int, default=1, choices=[1, 2], help="proofs submitted together (zk_transcript_seal_pair): 2 = the Fr phases of two consecutive "
                     "proofs share their launches; every proof is still its own batch-256 proof with its own transcript and digest row")
     ap.add_argument("--inflight", type=int, default=4, help="transcripts rotated by the pipelined loop (proofs whose G1 phase may still be running)")
@@ -491,7 +493,7 @@ def main():
     # Derived round commitments trade a longer G1 phase per proof (~11 ms instead of ~5) for less vector work: worth it while there
     # are later proofs to hide it under.  The LAST proofs of the run have none, so they take the short G1 phase (every T_r as an MSM):
     # the pipeline then drains in one MSM chain instead of two.
-    drain_from = args.steps - 3 if derive else args.steps
+    drain_from = args.steps - args.drain if derive else args.steps
     t0 = time.perf_counter()
     i = 0
     while i < args.steps:
