@@ -362,6 +362,7 @@ def main():
                     help="independent (default, the bench contract): every rank proves its own batches, one all-reduce of the run aggregate; "
                          "shard: the N ranks prove ONE batch together, sharded by batch rows (zkdl_amd/shard.py: strong scaling of a single proof, "
                          "two small all-gathers per proof, synchronous orchestration -- a functional mode, not the headline)")
+    ap.add_argument("--no-prewarm", action="store_true", help="skip the throw-away process that initialises torch on the GPU before this one does (see below)")
     ap.add_argument("--launcher-selftest", type=int, default=None, metavar="FAIL_RANK",
                     help="CPU-only check of the N-rank launch path (tests/test_dist_aggregate.py): gloo all-reduce of per-rank digests, no GPU work; "
                          "FAIL_RANK >= 0 makes that rank exit with status 3 before the rendezvous")
@@ -370,13 +371,22 @@ def main():
     # The first compute process on a freshly leased box runs ~12 % slow for its whole lifetime (5.2 vs 4.6 ms per proof over 20 steps;
     # any later process is not affected).  A 0.1 s helper (zkdl_amd/lib/gpu_touch: malloc, one kernel, exit) takes that role, BEFORE
     # this process -- or the ranks it spawns -- touch the GPU.  Setup work, like the commitments: not part of any timed region.
+    # Measured again at the end of round 2 (tools/first_run.sh): it is the first process that initialises TORCH on the GPU that runs slow --
+    # 4.5-4.6 instead of 3.95 ms per step over 20 steps, for its whole lifetime, a 6 s in-process spin-up does not help, the library's own
+    # processes (pytest -m gpu, smoke) before it do not help, gpu_touch does not help -- and a throw-away process that creates one CUDA tensor
+    # removes it.  So that is what runs first here (~3 s; --no-prewarm disables it and reports the cold figure).
     touch = os.path.join(ROOT, "zkdl_amd", "lib", "gpu_touch")
-    if args.launcher_selftest is None and os.path.exists(touch):
+    if args.launcher_selftest is None:
         if "WORLD_SIZE" not in os.environ:        # this process is the only rank, or the parent of the ranks it spawns below
-            for dev in range(max(1, args.gpus if not args.same_device else 1)):
-                subprocess.run([touch, str(dev)], timeout=60, check=False)
+            devs = [str(d) for d in range(max(1, args.gpus if not args.same_device else 1))]
         else:                                     # a rank under torch.distributed.run: its own device
-            subprocess.run([touch, "0" if args.same_device else os.environ.get("LOCAL_RANK", "0")], timeout=60, check=False)
+            devs = ["0" if args.same_device else os.environ.get("LOCAL_RANK", "0")]
+        for dev in devs:
+            if os.path.exists(touch):
+                subprocess.run([touch, dev], timeout=60, check=False)
+            if not args.no_prewarm:
+                subprocess.run([sys.executable, "-c", "import torch; x = torch.zeros((64, 8), dtype=torch.int64, device='cuda:%s'); x.sum().item(); torch.cuda.synchronize()" % dev],
+                               timeout=300, check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
@@ -613,7 +623,7 @@ def main():
            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (Fr) / u32x12 (Fp) limbs",
            "data": "synthetic",
            "config": {"workload": args.workload, "dims": dims, "batch_per_gpu": batch, "parallelism": "independent proofs per rank, one RCCL all-reduce of the run aggregate",
-                      "msm": args.msm, "derive_rounds": bool(derive), "inflight": args.inflight, "proofs_per_submission": 2 if paired else 1},
+                      "msm": args.msm, "derive_rounds": bool(derive), "inflight": args.inflight, "proofs_per_submission": 2 if paired else 1, "prewarm_process": not args.no_prewarm},
            "ms_per_proof": ms_per_step, "per_rank_ms_per_proof": per_rank_ms, "collective_world_size": (dist.get_world_size() if world > 1 else 1),
            "collective_backend": (dist.get_backend() if world > 1 else None),
            "host_enqueue_ms_per_step": t_enq * 1e3 / max(args.steps, 1), "aggregate_fr": hex(aggregate), "setup": wl.info, "roofline": roofline, "kernels": kernels,

@@ -525,7 +525,7 @@ static int run_sumcheck(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n,
       // fixed split: every big round r (< nbig) needs c_r = s - 1 - r >= 0
       // (with the 29-bit-limb rounds a workgroup covers 2^11 pairs: a wide low table keeps the high weight constant per workgroup)
       s = nbig;
-      static const bool wide_split = getenv("ZKDL_SC29_NARROW") == nullptr;  // A/B switch
+      static const bool wide_split = getenv("ZKDL_SC29_NARROW") == nullptr;  // A/B switch: keep the split at the number of big rounds (no factored weights then)
       if (sc29_enabled() && wide_split && k >= 6 && k - 6 > s) s = k - 6;
       if (s > k) s = k;
       if (!tabA.alloc(ctx, (size_t)1 << s) || !tabB.alloc(ctx, (size_t)1 << (k - s))) return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: sumcheck weights");
@@ -590,7 +590,7 @@ static int run_sumcheck(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n,
             prev_blocks, prev_cols, prev_dst)
     if (R == 3) ZK_SC_LAUNCH(3);
     else if (R == 2) ZK_SC_LAUNCH(2);
-    else if (!sc29_enabled() || getenv("ZKDL_SC29_OLDKERNEL")) ZK_SC_LAUNCH(1);
+    else if (!sc29_enabled()) ZK_SC_LAUNCH(1);
     else {
       // SC29_PPT pairs per lane, but at least 64 workgroups while each still gets a full 256 pairs (the factored weights
       // need 2^(k-s) = 64 of them)
