@@ -492,8 +492,11 @@ def main():
             i += 1
         if derive:
             zk.lib.zk_set_flag(zk.ctx, b"derive_rounds", 1)
-    if world > 1:                                # warm the communicator outside the timed region
-        dist.all_reduce(scratch_rows[-1], op=dist.ReduceOp.SUM)
+    # warm what closes the timed region as well: the row sum is a torch kernel whose first launch in a process loads its code object
+    # (~7 ms measured: 0.35 ms per step of a 20-step run; tools/notorch_bench.py runs the same loop without torch: 3.52 ms per proof at K = 20 and K = 100)
+    warm_agg = rows[:args.steps].sum(dim=0)
+    if world > 1:                                # ... and the communicator
+        dist.all_reduce(warm_agg, op=dist.ReduceOp.SUM)
     barrier()
     # keep the collector out of the timed region: a generation-2 pass over torch's object graph costs ~40 ms,
     # i.e. several whole proofs (seen as a one-off stall inside pure host code)
