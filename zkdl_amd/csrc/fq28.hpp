@@ -205,7 +205,7 @@ ZK_HD Fq fq_add(const Fq& a, const Fq& b) {
   for (int i = 0; i < 14; i++) r.v[i] = a.v[i] + b.v[i];
   return r;
 }
-// a + K p - b,  b normalised with value(b) <= K p / 2:  value < value(a) + K p,  limbs < max_limb(a) + 2^29
+// a + K p - b,  b normalised with value(b) <= (K - 1) p:  value < value(a) + K p,  limbs < max_limb(a) + 2^29
 template <uint32_t K>
 ZK_HD Fq fq_sub(const Fq& a, const Fq& b) {
   constexpr fq28::SubConst C = fq28::sub_const(K, 1);
@@ -214,7 +214,7 @@ ZK_HD Fq fq_sub(const Fq& a, const Fq& b) {
   for (int i = 0; i < 14; i++) r.v[i] = a.v[i] - b.v[i] + C.v[i];
   return r;
 }
-// a + K p - b - c - c  (b, c normalised, value(b) + 2 value(c) <= K p / 2): limbs < max_limb(a) + 2^30
+// a + K p - b - c - c  (b, c normalised, value(b) + 2 value(c) <= (K - 1) p): limbs < max_limb(a) + 2^30
 template <uint32_t K>
 ZK_HD Fq fq_sub3(const Fq& a, const Fq& b, const Fq& c) {
   constexpr fq28::SubConst C = fq28::sub_const(K, 3);
@@ -223,7 +223,7 @@ ZK_HD Fq fq_sub3(const Fq& a, const Fq& b, const Fq& c) {
   for (int i = 0; i < 14; i++) r.v[i] = a.v[i] - b.v[i] - (c.v[i] << 1) + C.v[i];
   return r;
 }
-// a + K p - b - c  (b, c normalised, value(b) + value(c) < K p)
+// a + K p - b - c  (b, c normalised, value(b) + value(c) <= (K - 1) p)
 template <uint32_t K>
 ZK_HD Fq fq_sub2(const Fq& a, const Fq& b, const Fq& c) {
   constexpr fq28::SubConst C = fq28::sub_const(K, 2);
@@ -232,7 +232,7 @@ ZK_HD Fq fq_sub2(const Fq& a, const Fq& b, const Fq& c) {
   for (int i = 0; i < 14; i++) r.v[i] = a.v[i] - b.v[i] - c.v[i] + C.v[i];
   return r;
 }
-// a + K p - 8 c  (c normalised, 8 value(c) < K p): limbs < max_limb(a) + 2^31 + 2^28
+// a + K p - 8 c  (c normalised, 8 value(c) <= (K - 1) p): limbs < max_limb(a) + 2^31 + 2^28
 template <uint32_t K>
 ZK_HD Fq fq_sub8(const Fq& a, const Fq& c) {
   constexpr fq28::SubConst C = fq28::sub_const(K, 8);

@@ -41,8 +41,8 @@ ZK_HD constexpr uint32_t R(int i) { return limb_of([](int j) constexpr { return 
 ZK_HD constexpr uint32_t ONE(int i) { return limb_of([](int j) constexpr { return FrP::ONE(j); }, i); }  // 2^256 mod r
 static_assert(FrP::INV == 0xffffffffu, "m = -t mod 2^29 below relies on r = 1 mod 2^32");
 static_assert(R(0) == 1u, "r = 1 mod 2^29");
-// K*r arranged for carry-free subtraction of NSUB normalised values (see fq28.hpp:sub_const); K >= 2 * (sum of the
-// subtrahends' bounds in units of r)
+// K*r arranged for carry-free subtraction of NSUB normalised values (see fq28.hpp:sub_const); K >= (sum of the
+// subtrahends' bounds in units of r) + 1
 struct SubConst {
   uint32_t v[9];
 };
@@ -101,7 +101,7 @@ ZK_HD Fs fs_add(const Fs& a, const Fs& b) {
   for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + b.v[i];
   return r;
 }
-// a + K r - b, b normalised with value(b) <= K r / 2
+// a + K r - b, b normalised with value(b) <= (K - 1) r
 template <uint32_t K>
 ZK_HD Fs fs_sub(const Fs& a, const Fs& b) {
   constexpr fs29::SubConst C = fs29::sub_const(K, 1);
