@@ -98,19 +98,20 @@ def test_fr_random_is_canonical_and_reproducible(zk):
 
 
 # ------------------------------------------------------------------ sumchecks
-@pytest.mark.parametrize("n,k", [(1, 0), (8, 3), (6, 3), (2048, 11), (1500, 11), (5000, 13)])
+@pytest.mark.parametrize("n,k", [(1, 0), (8, 3), (6, 3), (2048, 11), (1500, 11), (5000, 13), (100000, 17)])
 def test_sumcheck_ip(zk, oracle, rng, n, k):
     a, b, u = rand_fr(rng, n), rand_fr(rng, n), rand_fr(rng, k)
     assert eq(zk.sumcheck_ip(zk.upload(a), zk.upload(b), u), oracle.ip_sumcheck(a, b, u))
 
 
-@pytest.mark.parametrize("n,k", [(1, 0), (8, 3), (7, 3), (4096, 12), (3000, 12), (9000, 14)])
+# (131072, 17) and (100000, 17): big rounds whose workgroups take the factored-weight path of k_sc_round29 (one high weight per workgroup)
+@pytest.mark.parametrize("n,k", [(1, 0), (8, 3), (7, 3), (4096, 12), (3000, 12), (9000, 14), (131072, 17), (100000, 17)])
 def test_sumcheck_hadamard(zk, oracle, rng, n, k):
     a, b, u, v = rand_fr(rng, n), rand_fr(rng, n), rand_fr(rng, k), rand_fr(rng, k)
     assert eq(zk.sumcheck_hadamard(zk.upload(a), zk.upload(b), u, v), oracle.hp_sumcheck(a, b, u, v))
 
 
-@pytest.mark.parametrize("n,k", [(1, 0), (16, 4), (12, 4), (8192, 13), (5001, 13)])
+@pytest.mark.parametrize("n,k", [(1, 0), (16, 4), (12, 4), (8192, 13), (5001, 13), (131072, 17), (100000, 17)])
 def test_sumcheck_binary(zk, oracle, rng, n, k):
     bits = rng.integers(0, 2, size=n)
     one = oracle.constants()["fr_one"]
