@@ -29,7 +29,8 @@ static G1J point() {
   return p;
 }
 static void show_point(const G1Q& q) {
-  G1J c = g1q_canonical(q);
+  Fq tab[16];
+  G1J c = g1q_canonical(q, tab, 1);
   show(c.x); show(c.y); show(c.z);
 }
 int main() {
@@ -43,7 +44,8 @@ int main() {
     } else if (op == "sqr" || op == "inv") {
       std::string a; std::cin >> a;
       Fq x = fq_from_fp(parse(a));
-      show(fq_to_fp(op == "sqr" ? fq_sqr(x) : fq_inv(x)));
+      Fq tab[16];
+      show(fq_to_fp(op == "sqr" ? fq_sqr(x) : fq_inv(x, tab, 1)));
     } else if (op == "dbl") {
       show_point(g1q_double(g1q_from_jacobian(point())));
     } else if (op == "add") {

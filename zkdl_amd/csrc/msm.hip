@@ -546,11 +546,12 @@ __global__ void __launch_bounds__(64) k_msm_weighted(const MsmJob* __restrict__ 
 
 // canonical form in place: affine x, y with Z = ONE; infinity as {0, ONE, 0}
 __global__ void __launch_bounds__(64) k_g1_canonicalise(G1J* __restrict__ pts, uint32_t n) {
+  __shared__ Fq wtab[16 * 64];  // a^1 .. a^15 of every lane's inversion (fq_inv): 56 KB
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   G1J p = pts[i];
   if (!l_is_zero(p.z) && l_eq(p.z, fp_one())) return;
-  pts[i] = g1q_canonical(g1q_from_jacobian(p));  // the inversion's ~570 dependent products in the 28-bit-limb form (g1q.hpp)
+  pts[i] = g1q_canonical(g1q_from_jacobian(p), wtab + threadIdx.x, 64);  // the inversion's ~485 dependent products in the 28-bit-limb form (g1q.hpp)
 }
 int g1_canonicalise_dev(zk_ctx* ctx, G1J* pts, uint32_t n) {
   if (n) ZK_LAUNCH(ctx, "g1_canonicalise", 288ull * n, k_g1_canonicalise, dim3((n + 63) / 64), dim3(64), 0, pts, n);
