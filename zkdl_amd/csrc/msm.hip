@@ -41,7 +41,10 @@
 
 namespace zk {
 
-static constexpr uint32_t MSM_CHUNK = 16;  // items per lane in k_msm_accum
+#ifndef ZK_MSM_CHUNK
+#define ZK_MSM_CHUNK 24
+#endif
+static constexpr uint32_t MSM_CHUNK = ZK_MSM_CHUNK;  // items per lane in k_msm_accum
 #ifndef ZK_ACCUM_INLINE
 #define ZK_ACCUM_INLINE 1
 #endif
