@@ -42,7 +42,7 @@
 namespace zk {
 
 #ifndef ZK_MSM_CHUNK
-#define ZK_MSM_CHUNK 24
+#define ZK_MSM_CHUNK 16
 #endif
 static constexpr uint32_t MSM_CHUNK = ZK_MSM_CHUNK;  // items per lane in k_msm_accum
 #ifndef ZK_ACCUM_INLINE
