@@ -567,6 +567,14 @@ def test_paired_sealing_zips_two_proofs_without_changing_them(zk, oracle):
     zk.set_flag("lanes", 1)
     check(0, 4)
     check(1, 5)
+    # a transcript cannot be its own partner; the failed call leaves both usable
+    from zkdl_amd.capi import ZkError
+    with pytest.raises(ZkError):
+        trs[0].seal_pair(trs[0], lanes[0].ptr, lanes[0].ptr)
+    trs[0].reset()
+    enqueue_proof(st, chals[2], trs[0])
+    trs[0].seal(lanes[0].ptr)
+    check(0, 2)
 
 
 def test_recorded_batched_layers_equal_immediate_execution(zk, oracle):
