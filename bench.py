@@ -129,7 +129,9 @@ class Workload:
         """Fresh challenge vectors in the reference's draw order (zkfc.cu:135-137, zkrelu.cu:85-98)."""
         zk, sh, L = self.zk, self.shapes, len(self.shapes)
         kb = ceil_log2(self.B_p)
-        zk.seed(0xC0FFEE + (step & 0xffffff))    # a function of the step alone: the run aggregate does not depend on how many spin-up proofs ran
+        # a function of the step alone (the run aggregate does not depend on how many spin-up proofs ran), in a seed domain of its own
+        # (the generator randomisers draw from 0xC0FFEE + rank)
+        zk.seed(0x5EEDC4A100000000 + (step & 0xffffffff))
 
         def fc(s):
             return [zk.random_vec(kb), zk.random_vec(ceil_log2(s["in_p"])), zk.random_vec(ceil_log2(s["out_p"]))]
@@ -170,13 +172,17 @@ def _rv(rng, n):
     return a
 
 
-def cpu_baseline(zk, wl, mode="sample"):
-    """Time the oracle (CPU restatement of the reference algorithm, OpenMP over tensor elements) on the SAME
-    workload at the SAME batch size.  mode "sample": FC[L-1] + ReLU[L-2] + FC[L-2] of the timed loop (demo.cu:124-138),
-    inputs = this workload's own activations / weights / generators / commitments downloaded from the device;
-    the rest of the loop is extrapolated -- FC calls by their G1 scalar-mul count (m + 5 n_gens per layer, SURVEY 8d:
-    the opening dominates and is batch-independent), ReLU calls by their element count.  mode "full": every call."""
+def cpu_baseline(zk, wl, mode="full", parity=None, calls=None):
+    """Time the oracle (CPU restatement of the reference algorithm, OpenMP over tensor elements) on the SAME workload at the SAME
+    batch size, and -- `parity` = (challenges, Fr, affine G1, infinity flags) of ONE GPU proof made in the benchmarked configuration --
+    compare what it returns with that proof, call by call: Fr slices bit for bit, G1 slices in affine-canonical form.
+    mode "full": every call of the timed loop (demo.cu:124-138), nothing extrapolated.  mode "sample": FC[L-1] + ReLU[L-2] + FC[L-2],
+    inputs = this workload's own activations / weights / generators / commitments downloaded from the device; the rest of the loop is
+    extrapolated -- FC calls by their G1 scalar-mul count (m + 5 n_gens per layer, SURVEY 8d: the opening dominates and is
+    batch-independent), ReLU calls by their element count.
+    Returns (cpu_baseline object, parity_checked object or None)."""
     from oracle.oracle_py import Oracle
+    from zkdl_amd.proof import split_calls
     orc = Oracle()
     sh = wl.shapes
     L = len(sh)
@@ -185,39 +191,86 @@ def cpu_baseline(zk, wl, mode="sample"):
     kb = ceil_log2(B_p)
     layers = list(range(L)) if mode == "full" else [L - 1, L - 2]
     relus = list(range(L - 1)) if mode == "full" else [L - 2]
+    if calls is not None:                                    # an explicit list of (kind, layer): tests
+        layers = [i for kind, i in calls if kind == "fc"]
+        relus = [i for kind, i in calls if kind == "relu"]
+    by_call, gpu = {}, {}
+    if parity is not None:
+        chal, fr_g, aff_g, inf_g = parity
+        by_call = {(kind, i): ch for kind, i, ch in chal}
+        gpu = {(kind, i): (f, a, nf) for kind, i, f, a, nf in split_calls(wl.dims, wl.batch, fr_g, aff_g, inf_g)}
+    checked = {"calls": [], "fr": 0, "g1": 0, "ok": True, "mismatch": []}
+
+    def check(kind, i, fr_o, g1_o=None):
+        if parity is None:
+            return
+        f, a, nf = gpu[(kind, i)]
+        name = "%s%d" % ("zkFC" if kind == "fc" else "zkReLU", i)
+        good = fr_o.shape == f.shape and np.array_equal(fr_o, f)
+        if g1_o is not None:
+            aff_o, inf_o = orc.g1_to_affine(g1_o)
+            good = good and aff_o.shape == a.shape and np.array_equal(aff_o, a) and np.array_equal(inf_o, nf)
+            checked["g1"] += int(a.shape[0])
+        checked["fr"] += int(f.shape[0])
+        checked["calls"].append(name)
+        if not good:
+            checked["ok"] = False
+            checked["mismatch"].append(name)
+
     t_fc = t_relu = 0.0
     t_start = time.perf_counter()
-    for i in sorted(set(layers), reverse=True):
+    for i in sorted(set(layers) | set(relus), reverse=True):
         s = sh[i]
+        if i not in layers:                                  # a ReLU call on its own
+            Z = wl.Z[i].download()
+            A_, sign, mag, rem = orc.relu_forward(Z)
+            k = ceil_log2(B_p * s["out_p"])
+            ch = by_call.get(("relu", i)) or [_rv(rng, n) for n in (k + 5, k + 5, k + 4, k + 4, k, k, k)]
+            t0 = time.perf_counter()
+            fr_o = orc.relu_prove(Z, A_, sign, mag, rem, *ch)
+            t_relu += time.perf_counter() - t0
+            check("relu", i, fr_o)
+            del A_, sign, mag, rem
+            continue
         W = wl.fcs[i].weights().download()
         gens = wl.gens[i].points().download()
         com = wl.fcs[i].com().download()
         X = (wl.A[i - 1] if i > 0 else wl.X).download()
         Z = (wl.Yhat if i == L - 1 else wl.Z[i]).download()
+        ch = by_call.get(("fc", i)) or [_rv(rng, kb), _rv(rng, ceil_log2(s["in_p"])), _rv(rng, ceil_log2(s["out_p"]))]
         t0 = time.perf_counter()
-        orc.fc_prove(X, Z, W, s["in_p"], s["out_p"], gens, com, _rv(rng, kb), _rv(rng, ceil_log2(s["in_p"])), _rv(rng, ceil_log2(s["out_p"])))
+        fr_o, g1_o = orc.fc_prove(X, Z, W, s["in_p"], s["out_p"], gens, com, *ch)
         t_fc += time.perf_counter() - t0
+        check("fc", i, fr_o, g1_o)
         del W, gens, com, X
         if i in relus:
             A_, sign, mag, rem = orc.relu_forward(Z)            # aux tensors as the reference stores them (untimed: inference)
             k = ceil_log2(B_p * s["out_p"])
+            ch = by_call.get(("relu", i)) or [_rv(rng, n) for n in (k + 5, k + 5, k + 4, k + 4, k, k, k)]
             t0 = time.perf_counter()
-            orc.relu_prove(Z, A_, sign, mag, rem, *[_rv(rng, n) for n in (k + 5, k + 5, k + 4, k + 4, k, k, k)])
+            fr_o = orc.relu_prove(Z, A_, sign, mag, rem, *ch)
             t_relu += time.perf_counter() - t0
+            check("relu", i, fr_o)
             del A_, sign, mag, rem
     wall = time.perf_counter() - t_start
     g1_cost = lambda s_: s_["m"] + 5 * s_["n_gens"]
-    fc_scale = sum(g1_cost(s_) for s_ in sh) / sum(g1_cost(sh[i]) for i in layers)
+    fc_scale = sum(g1_cost(s_) for s_ in sh) / max(sum(g1_cost(sh[i]) for i in layers), 1)
     relu_scale = sum(B_p * sh[i]["out_p"] for i in range(L - 1)) / max(sum(B_p * sh[i]["out_p"] for i in relus), 1)
     total_s = t_fc * fc_scale + t_relu * relu_scale
     what = ("the whole prove loop (%d zkFC::prove + %d zkReLU::prove calls)" % (L, L - 1)) if mode == "full" else \
            ("zkFC::prove of layers %d,%d + zkReLU::prove of layer %d" % (L - 1, L - 2, L - 2))
-    return {"value": total_s * 1e3 / wl.batch, "unit": "ms/example (batch %d)" % wl.batch, "cores": orc.num_threads(), "kind": "port",
+    base = {"value": total_s * 1e3 / wl.batch, "unit": "ms/example (batch %d)" % wl.batch, "cores": orc.num_threads(), "kind": "port",
             "sample": "oracle (CPU restatement of the reference algorithm) on %s of this workload at batch %d: FC %.1f s + ReLU %.1f s measured "
                       "(%.0f s wall incl. downloads and the untimed aux-tensor pass); %s; the reference's CUDA binary cannot run here (no NVIDIA device)"
                       % (what, wl.batch, t_fc, t_relu, wall,
                          "nothing extrapolated" if mode == "full" else "extrapolated to all %d + %d calls: FC x%.2f by G1 scalar-mul count, ReLU x%.2f by element count" % (L, L - 1, fc_scale, relu_scale)),
             "ms_per_proof": total_s * 1e3, "measured_fc_s": t_fc, "measured_relu_s": t_relu, "extrapolated": mode != "full"}
+    return base, (checked if parity is not None else None)
+
+
+def cpu_baseline_check_only(zk, wl, calls, parity):
+    """The oracle comparison alone, for an explicit list of (kind, layer) calls."""
+    return cpu_baseline(zk, wl, "sample", parity, calls=calls)
 
 
 def msm_fullwidth_probe(zk, log_pairs=24):
@@ -341,7 +394,10 @@ def main():
     ap.add_argument("--workload", default="mlp18m_b256", choices=sorted(WORKLOADS))
     ap.add_argument("--msm", default="pippenger", choices=["pippenger", "literal"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "off"], help="oracle timed on a layer subset at the bench's batch size (default), on the whole loop, or not at all")
+    ap.add_argument("--cpu-baseline", default="full", choices=["sample", "full", "off"], help="oracle timed on the whole prove loop at the bench's batch size (default: ~1 min on the "
+                    "GPU box's host, nothing extrapolated), on a layer subset (extrapolated), or not at all; either way its outputs are compared with one GPU proof (parity_checked)")
+    ap.add_argument("--steady-steps", type=int, default=120, help="proofs of the longer of the two untimed runs the steady-state figure is taken from (0 = skip)")
+    ap.add_argument("--latency-reps", type=int, default=5, help="single proofs (nothing else in flight) timed for latency_ms_per_proof (0 = skip)")
     ap.add_argument("--no-msm-probe", action="store_true", help="skip the full-width 2^24-pair zk_msm_batch throughput probe")
     ap.add_argument("--spinup-ms", type=float, default=400.0, help="untimed proofs before the W warm-up steps until this much wall time has passed: the first process on a "
                     "fresh box otherwise runs its first ~100 ms 12 %% slow (GPU power state); 0 disables")
@@ -381,12 +437,26 @@ def main():
             devs = [str(d) for d in range(max(1, args.gpus if not args.same_device else 1))]
         else:                                     # a rank under torch.distributed.run: its own device
             devs = ["0" if args.same_device else os.environ.get("LOCAL_RANK", "0")]
+        # all devices at once (N serial ~3 s helpers were N x 3 s of start-up before an 8-GPU run)
+        helpers = []
         for dev in devs:
-            if os.path.exists(touch):
-                subprocess.run([touch, dev], timeout=60, check=False)
-            if not args.no_prewarm:
-                subprocess.run([sys.executable, "-c", "import torch; x = torch.zeros((64, 8), dtype=torch.int64, device='cuda:%s'); x.sum().item(); torch.cuda.synchronize()" % dev],
-                               timeout=300, check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            if os.path.exists(touch) and not args.no_prewarm:   # --no-prewarm: no helper process at all (profiler passes: children would be traced too)
+                helpers.append(subprocess.Popen([touch, dev]))
+        for h in helpers:
+            try:
+                h.wait(timeout=60)
+            except subprocess.TimeoutExpired:
+                h.kill()
+        helpers = []
+        if not args.no_prewarm:
+            for dev in devs:
+                helpers.append(subprocess.Popen([sys.executable, "-c", "import torch; x = torch.zeros((64, 8), dtype=torch.int64, device='cuda:%s'); x.sum().item(); torch.cuda.synchronize()" % dev],
+                                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
+        for h in helpers:
+            try:
+                h.wait(timeout=300)
+            except subprocess.TimeoutExpired:
+                h.kill()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
@@ -443,7 +513,8 @@ def main():
         zk.set_flag("lanes", 0)
     nprof = max(1, min(args.steps, args.prof_steps))
     rows = torch.zeros((args.steps + 1, 8), dtype=torch.int64, device="cuda")
-    scratch_rows = torch.zeros((max(args.warmup, 1) + 4 * nprof + 8, 8), dtype=torch.int64, device="cuda")
+    scratch_rows = torch.zeros((max(args.warmup, 1) + 4 * nprof + 8 + 16, 8), dtype=torch.int64, device="cuda")
+    extra_rows = scratch_rows.data_ptr() + 64 * (max(args.warmup, 1) + 4 * nprof + 8)     # 16 rows for the untimed side measurements below
     rows_base, scratch_base = rows.data_ptr(), scratch_rows.data_ptr()
     torch.cuda.synchronize()
 
@@ -536,9 +607,62 @@ def main():
         elapsed = max(float(x.item()) for x in allt)
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
     value = ms_per_step / (batch * world)
+    rank_devices = [local_rank]
+    if world > 1:                                        # which device every rank proved on, as the ranks themselves report it
+        dv = torch.tensor([torch.cuda.current_device()], dtype=torch.int64, device="cuda")
+        alld = [torch.zeros_like(dv) for _ in range(world)]
+        dist.all_gather(alld, dv)
+        rank_devices = [int(x.item()) for x in alld]
     aggregate = lanes_to_fr(agg.cpu().tolist())
     if os.environ.get("ZKDL_BENCH_DUMP_ROWS"):       # per-proof digests, for run-to-run comparisons
         np.save(os.environ["ZKDL_BENCH_DUMP_ROWS"], rows[:args.steps].cpu().numpy())
+
+    # ---- side measurements, all OUTSIDE the timed region (same process, same workload):
+    #  * steady_state_ms_per_proof: two untimed runs of N/3 and N proofs; the difference of their wall times over the difference of their
+    #    lengths cancels the pipeline's fill and drain, which the K-step headline pays (ms_per_step above).
+    #  * latency_ms_per_proof: ONE proof with nothing else in flight, host-timed from the first prove call to the end of its G1 phase -- the
+    #    reference's own definition of its metric (demo.cu:124-140 times one prove loop); both forms of the opening's round commitments.
+    gc.disable()
+
+    def run_n(n, base_step):
+        zk.sync()
+        t = time.perf_counter()
+        for j in range(n):
+            step(base_step + j, extra_rows + 64 * (j % len(wl.trs)))
+        zk.sync()
+        return (time.perf_counter() - t) * 1e3
+
+    steady = None
+    if args.steady_steps >= 12 and pipelined and not paired:
+        n_long, n_short = args.steady_steps, max(4, args.steady_steps // 3)
+        t_short = run_n(n_short, 40_000)
+        t_long = run_n(n_long, 50_000)
+        steady = {"ms_per_proof": (t_long - t_short) / (n_long - n_short), "runs": {str(n_short): t_short, str(n_long): t_long},
+                  "how": "(wall of %d proofs - wall of %d proofs) / %d, both untimed runs after the timed region, derive_rounds as benchmarked, no drain form" % (n_long, n_short, n_long - n_short)}
+    latency = None
+    if args.latency_reps > 0:
+        latency = {}
+        for name, flag in (("msm_rounds", 0), ("derive_rounds", 1)):
+            if flag and not derive:
+                continue
+            zk.set_flag("derive_rounds", flag)
+            ts = [run_n(1, 60_000 + 100 * flag + j) for j in range(args.latency_reps + 1)][1:]
+            latency[name] = {"median_ms": float(np.median(ts)), "min_ms": float(min(ts)), "reps": len(ts)}
+        zk.set_flag("derive_rounds", 1 if derive else 0)
+        latency["definition"] = "one batch-%d proof, nothing else in flight: host wall time from the first prove call until its G1 phase has finished (demo.cu:124-140)" % batch
+    # ---- the proof the CPU oracle is compared with: made in the benchmarked configuration, with len(trs) proofs in flight around it
+    parity_src = None
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_baseline != "off"
+    if want_cpu and args.msm == "pippenger":
+        P = 70_000
+        nfl = len(wl.trs) if pipelined else 1
+        for j in range(nfl):
+            step(P - (nfl - 1) + j, extra_rows + 64 * (8 + j % 8))
+        trp = wl.trs[P % len(wl.trs)] if pipelined else wl.tr
+        fr_p, _ = trp.read()
+        aff_p, inf_p = trp.read_affine()
+        parity_src = (wl.challenges(P), fr_p, aff_p, inf_p)
+    gc.enable()
 
     # ---- per-kernel device time (HIP events on the launching stream).  Two passes over the same steps:
     #  * standalone: worker streams off, so every launch runs alone on the chip -- this is the duration a
@@ -566,70 +690,129 @@ def main():
     kernels = {k: {"ms_per_step": v["ms"] / nprof, "share": v["ms"] / total_ms, "launches_per_step": v["launches"] // nprof,
                    "alg_GBps": (v["bytes"] / v["ms"] / 1e6) if v["ms"] > 0 else 0.0,
                    "concurrent_ms_per_step": (prof_conc[k]["ms"] / nprof) if k in prof_conc else None} for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
-    # ---- roofline of the dominant kernel family of the timed region.  Every family on this path is wide-integer
-    # modular arithmetic and measures integer-VALU bound (profiles/: SQ counters), so the bound is "valu":
-    #   achieved = ALGORITHMIC 32x32->64 MACs per launch (Montgomery products the kernel's algorithm needs x MACs per
-    #   product) / average launch duration (HIP events on the launching stream, standalone launches)
+    # ---- rooflines.  Every family on this path is wide-integer modular arithmetic and measures integer-VALU bound (profiles/: SQ
+    # counters), so the bound is "valu":
+    #   achieved = ALGORITHMIC 32x32->64 MACs per launch (Montgomery products the kernel's algorithm needs x MACs per product in the
+    #              problem's own 32-bit words: 136 for Fr, 300 for Fp) / average launch duration (HIP events on the
+    #              launching stream, standalone launches)
     #   peak     = measured v_mad_u64_u32 issue peak (tools/instr_rate.hip)
-    # The HBM view of the same kernel (algorithmic bytes / duration vs 8 TB/s, PMC traffic) is kept under "hbm".
-    # family -> substrings that identify its kernel in rocprofv3's (mangled) names, Fr products per 32-byte element read
+    # `roofline_all` lists every family that has a model; `roofline` is the family with the most device time per proof among them
+    # (whatever its occupancy), `roofline_chip_filling` the longest one whose launches fill the chip.  The HBM view of the same kernel
+    # (algorithmic bytes / duration vs 8 TB/s, PMC traffic) is kept under "hbm".
     # family -> (substrings identifying its kernel in rocprofv3's mangled names, algorithmic bytes per work unit, Fr products per unit):
     #   binary round: unit = a pair, 96 B (two reads + one write), 6 products (a0 w, da w, three coefficients, the fold; 7 when the weight does not factor)
     #   Hadamard / inner-product round: unit = a pair of both tables, 192 B, 7 / 5 products ; contraction: unit = an element, 32 B, 1 product
-    fam = {"sumcheck_bin_round": (["k_many", "k_sc_roundILi2ELi1E"], 96, 6), "sumcheck_hp_round": (["k_many", "k_sc_roundILi1ELi1E"], 192, 7),
+    fam = {"sumcheck_bin_round": (["k_many", "k_sc_round29ILi2E"], 96, 6), "sumcheck_hp_round": (["k_many", "k_sc_round29ILi1E"], 192, 7),
            "sumcheck_ip_round": (["k_many", "k_sc_roundILi0ELi1E"], 192, 5), "fr_contract": (["k_many", "k_colsum"], 32, 1),
            # byte-histogram pass: unit = one 32-bit magnitude word + one 16-bit remainder word (4 + 32 and 2 + 32 bytes), 7 + 3 products
            # (word weights for the sumcheck and the partial_me, the cross terms, the round-4 product, the folded output)
-           "binp_words": (["k_many", "k_binb_words"], 70, 10), "msm_accum": (["k_msm_accum"], 100, None)}
-    macs_per_launch = {}
+           "binp_words": (["k_many", "k_binb_words"], 70, 10), "msm_accum": (["k_msm_accum"], 100, None), "msm_combine": (["k_msm_combine"], None, None),
+           "msm_bucket_reduce": (["k_msm_rowcol"], None, None), "msm_horner": (["k_msm_weighted"], None, None), "msm_derive": (["k_derive_mul"], None, None),
+           "g1_canonicalise": (["k_g1_canonicalise"], None, None)}
+    macs_per_step = {}
     for k, v in prof.items():
         if k in fam and fam[k][2] is not None:
-            macs_per_launch[k] = v["bytes"] / max(v["launches"], 1) / fam[k][1] * fam[k][2] * FR_MACS
+            macs_per_step[k] = v["bytes"] / nprof / fam[k][1] * fam[k][2] * FR_MACS
     # MSM items of one proof: the launch is sized for n * W slots per job (its `bytes`), but T0_r / T1_r only touch every other
     # generator (their other scalars are zero and are dropped by the sort): per layer 2 k_lo n + n (T, T0, T1 of every round, the
     # final generator) + m (com(u_hi)) nonzero full-width scalars, 26 ten-bit windows each
     # (with derived round commitments all k full-size T_r MSMs are gone: (k + 1) n + m)
-    real_pairs = sum(((ceil_log2(s_["n_gens"]) + 1) if derive else (2 * ceil_log2(s_["n_gens"]) + 1)) * s_["n_gens"] + s_["m"] for s_ in wl.shapes)
-    if "msm_accum" in prof:
-        slots = prof["msm_accum"]["bytes"] / 100.0 / max(prof["msm_accum"]["launches"], 1)
-        items = min(slots, real_pairs * 26.0) if args.msm == "pippenger" and not args.msm_window else slots
-        macs_per_launch["msm_accum"] = items * 10 * FP_MACS   # 8M + 2S per XYZZ mixed add
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_r02c.json")
+    klo = [ceil_log2(s_["n_gens"]) for s_ in wl.shapes]
+    real_pairs = sum(((k_ + 1) if derive else (2 * k_ + 1)) * s_["n_gens"] + s_["m"] for k_, s_ in zip(klo, wl.shapes))
+    g1_model = None
+    if "msm_accum" in prof and args.msm == "pippenger":
+        c_win, W_win, chunk = (args.msm_window or 10), None, 16
+        W_win = (254 + 2 + c_win - 1) // c_win
+        slots = prof["msm_accum"]["bytes"] / 100.0 / nprof
+        items = min(slots, real_pairs * float(W_win))
+        n_jobs = sum((2 * k_ + 2) if derive else (3 * k_ + 2) for k_ in klo)          # MSMs of one proof (derived: T0_r, T1_r, final generator, com(u_hi))
+        B = 1 << (c_win - 1)
+        LB = c_win // 2
+        nlo, nhi = 1 << LB, (B >> LB) + 1
+        ADD, MADD, DBL = 14, 10, 9                                                    # XYZZ: 12M+2S, 8M+2S, 6M+3S (msm.hip)
+        JADD, JDBL, INV = 16, 7, 485                                                  # Jacobian 11M+5S, 2M+5S (g1q.hpp); Fermat inverse with 4-bit windows
+        n_derived = sum(k_ * k_ for k_ in klo) if derive else 0                       # coef * point products behind the batch (T_0 .. T_{k-1}: 2r + 1 each)
+        n_g1_out = sum(3 * k_ + 2 for k_ in klo)                                      # transcript points put into canonical form
+        g1_model = {"items": items, "jobs": n_jobs, "derived_products": n_derived, "points_canonicalised": n_g1_out, "window_bits": c_win, "windows": W_win}
+        macs_per_step["msm_accum"] = items * MADD * FP_MACS
+        # stitching: a bucket that spans chunks t0..t1 costs t1 - t0 additions: in total one per chunk boundary that falls inside a bucket (~ all of them)
+        macs_per_step["msm_combine"] = max(items / chunk - n_jobs, 0.0) * ADD * FP_MACS
+        macs_per_step["msm_bucket_reduce"] = 2.0 * B * n_jobs * ADD * FP_MACS         # every bucket enters one row sum and one column sum
+        # per MSM: c bit-slices of the row / column sums (half of the sums each), sum_j j doublings, a 15-addition tree, back to Jacobian (6 products)
+        macs_per_step["msm_horner"] = n_jobs * ((LB * (nlo // 2) + (c_win - LB) * ((nhi - 1) // 2) + 15) * ADD + (c_win * (c_win - 1) // 2) * DBL + 6) * FP_MACS
+        if n_derived and "msm_derive" in prof:
+            # per product: GLV halves on two lanes, each 128 doublings + 32 window additions + an 8-entry table (1 doubling + 6 additions); the halves' sum;
+            # then one addition per product into its T_r
+            macs_per_step["msm_derive"] = n_derived * (2 * (128 * JDBL + 32 * JADD + JDBL + 6 * JADD) + JADD + JADD) * FP_MACS
+        if "g1_canonicalise" in prof:
+            macs_per_step["g1_canonicalise"] = n_g1_out * (INV + 5) * FP_MACS         # 1/Z, Z^-2, Z^-3, x, y
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_r03.json")
     pmc_all = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
-    cands = [k for k in kernels if k in macs_per_launch] or list(kernels)[:1]
-    dom = max(cands, key=lambda k: kernels[k]["ms_per_step"])
-    if "msm_accum" in cands and kernels["msm_accum"]["ms_per_step"] >= 0.7 * kernels[dom]["ms_per_step"]:
-        dom = "msm_accum"   # the one launch that fills the chip; the sumcheck families are 18 small launches each (their rates are under other_kernels_TMACps)
-    pv = prof[dom]
-    avg_ms = pv["ms"] / max(pv["launches"], 1)
-    hbm_achieved = pv["bytes"] / pv["ms"] / 1e6 if pv["ms"] > 0 else 0.0
-    want = fam[dom][0] if dom in fam else [dom]
-    pmc_hit = None
-    for name, rec in pmc_all.get("kernels", {}).items():
-        if all(w in name for w in want):
-            pmc_hit = rec if pmc_hit is None or rec.get("launches", 0) > pmc_hit.get("launches", 0) else pmc_hit
-    traffic = (2.0 * pmc_hit["fetch_kb_per_launch"] + pmc_hit["write_kb_per_launch"]) * 1024.0 if pmc_hit and "fetch_kb_per_launch" in pmc_hit else None
-    achieved = macs_per_launch.get(dom, 0.0) / avg_ms / 1e9 if avg_ms > 0 else 0.0
-    roofline = {"kernel": dom, "bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TMACPS, "unit": "TMAC/s (32x32->64 integer multiply-accumulates per second)",
-                "frac": achieved / VALU_PEAK_TMACPS, "traffic": traffic, "avg_launch_ms": avg_ms, "alg_macs_per_launch": macs_per_launch.get(dom),
+
+    def pmc_of(family):
+        want = fam[family][0] if family in fam else [family]
+        hit = None
+        for name, rec in pmc_all.get("kernels", {}).items():
+            if all(w in name for w in want):
+                hit = rec if hit is None or rec.get("launches", 0) > hit.get("launches", 0) else hit
+        return hit
+
+    def roofline_of(k):
+        pv = prof[k]
+        launches = max(pv["launches"], 1)
+        avg_ms = pv["ms"] / launches
+        macs_launch = macs_per_step[k] * nprof / launches
+        ach = macs_launch / avg_ms / 1e9 if avg_ms > 0 else 0.0
+        hbm_ach = pv["bytes"] / pv["ms"] / 1e6 if pv["ms"] > 0 else 0.0
+        hit = pmc_of(k)
+        traffic = (2.0 * hit["fetch_kb_per_launch"] + hit["write_kb_per_launch"]) * 1024.0 if hit and "fetch_kb_per_launch" in hit else None
+        return {"kernel": k, "bound": "valu", "achieved": ach, "peak": VALU_PEAK_TMACPS, "unit": "TMAC/s (32x32->64 integer multiply-accumulates per second)",
+                "frac": ach / VALU_PEAK_TMACPS, "traffic": traffic, "avg_launch_ms": avg_ms, "alg_macs_per_launch": macs_launch, "ms_per_step": pv["ms"] / nprof,
                 "launches_per_step": pv["launches"] // nprof,
-                "measured": "standalone launches (worker streams off) after the timed region, HIP events on the launching stream; rocprofv3 of `bench.py --serial` agrees (profiles/)",
-                "concurrent_avg_launch_ms": (prof_conc[dom]["ms"] / max(prof_conc[dom]["launches"], 1)) if dom in prof_conc else None,
-                "hbm": {"achieved": hbm_achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBPS, "alg_bytes_per_launch": pv["bytes"] / max(pv["launches"], 1),
+                "concurrent_avg_launch_ms": (prof_conc[k]["ms"] / max(prof_conc[k]["launches"], 1)) if k in prof_conc else None,
+                "hbm": {"achieved": hbm_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_ach / HBM_PEAK_GBPS, "alg_bytes_per_launch": pv["bytes"] / launches,
                         "traffic_bytes_per_launch": traffic},
-                "pmc": {k: pmc_hit[k] for k in pmc_hit if k not in ("fetch_kb_per_launch", "write_kb_per_launch")} if pmc_hit else None,
-                "note": "wide-integer modular arithmetic: no MFMA mapping; HBM traffic (PMC) equals the algorithmic bytes, the SIMDs are instruction-issue bound "
-                        "(profiles/pmc_r02c.json: VALU busy); peak = measured issue rate of the MAC instruction, so frac is the share of issue slots doing algorithmic MACs",
-                "other_kernels_TMACps": {k: macs_per_launch[k] / (prof[k]["ms"] / max(prof[k]["launches"], 1)) / 1e9 for k in macs_per_launch if k != dom and prof[k]["ms"] > 0}}
+                "pmc": ({kk: hit[kk] for kk in hit if kk not in ("fetch_kb_per_launch", "write_kb_per_launch")} if hit else None),
+                "pmc_source": (("profiles/pmc_r03.json, collected at commit %s: a separate rocprofv3 --pmc run of this bench, not this run" % pmc_all.get("commit", "?")) if hit else None)}
+
+    modelled = [k for k in kernels if k in macs_per_step and prof[k]["ms"] > 0]
+    roofline_all = [roofline_of(k) for k in modelled]
+    for r_ in roofline_all:
+        kernels[r_["kernel"]]["alg_TMACps"] = r_["achieved"]
+        kernels[r_["kernel"]]["valu_frac"] = r_["frac"]
+    if modelled:
+        dom = max(modelled, key=lambda k: kernels[k]["ms_per_step"])
+        roofline = dict(roofline_of(dom))
+        # chip-filling: launches of at least ~4 waves per SIMD's worth of workgroups; on this path that is the accumulation and the big rounds
+        filling = [k for k in modelled if k in ("msm_accum", "sumcheck_bin_round", "sumcheck_hp_round", "binp_words", "fr_contract")]
+        fill = max(filling, key=lambda k: kernels[k]["ms_per_step"]) if filling else dom
+        roofline["measured"] = "standalone launches (worker streams off) after the timed region, HIP events on the launching stream; rocprofv3 of `bench.py --serial` agrees (profiles/)"
+        roofline["selection"] = "the family with the most device time per proof among all families with a MAC model (roofline_all); roofline_chip_filling = the longest family whose launches fill the chip"
+        roofline["note"] = ("wide-integer modular arithmetic: no MFMA mapping; HBM traffic (PMC) is at or below the algorithmic bytes (window tables hit L2), the SIMDs are "
+                            "instruction-issue bound; peak = measured issue rate of the MAC instruction, so frac is the share of issue slots doing algorithmic MACs. "
+                            "Families that run on a handful of waves (msm_derive, g1_canonicalise, msm_horner: dependent chains of field products) are latency-bound: "
+                            "their frac is the price of the chain, not of the instruction mix")
+        roofline_fill = roofline_of(fill)
+    else:
+        k0 = next(iter(kernels))
+        roofline = {"kernel": k0, "bound": "valu", "achieved": None, "peak": VALU_PEAK_TMACPS, "unit": "TMAC/s", "frac": None, "traffic": None,
+                    "avg_launch_ms": prof[k0]["ms"] / max(prof[k0]["launches"], 1), "note": "no MAC model for this configuration"}
+        roofline_fill = None
 
     out = {"metric": "proving ms/example (batch 256) on 18M-param MLP", "value": value, "unit": "ms/example", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (Fr) / u32x12 (Fp) limbs",
            "data": "synthetic",
            "config": {"workload": args.workload, "dims": dims, "batch_per_gpu": batch, "parallelism": "independent proofs per rank, one RCCL all-reduce of the run aggregate",
-                      "msm": args.msm, "derive_rounds": bool(derive), "inflight": args.inflight, "proofs_per_submission": 2 if paired else 1, "prewarm_process": not args.no_prewarm},
-           "ms_per_proof": ms_per_step, "per_rank_ms_per_proof": per_rank_ms, "collective_world_size": (dist.get_world_size() if world > 1 else 1),
-           "collective_backend": (dist.get_backend() if world > 1 else None),
-           "host_enqueue_ms_per_step": t_enq * 1e3 / max(args.steps, 1), "aggregate_fr": hex(aggregate), "setup": wl.info, "roofline": roofline, "kernels": kernels,
+                      "msm": args.msm, "derive_rounds": bool(derive), "inflight": args.inflight, "proofs_per_submission": 2 if paired else 1, "prewarm_process": not args.no_prewarm,
+                      "drain_form_proofs": (min(args.drain, args.steps) if derive else 0), "spinup_ms": args.spinup_ms, "spinup_proofs": n_spin,
+                      "warmup_drain_form_proofs": (min(2, args.warmup) if derive and args.warmup >= 2 else 0),
+                      "schedule_note": "the last drain_form_proofs proofs of the timed region run every round commitment as an MSM (derive_rounds off): they have no later proof to hide the derivation under"},
+           "ms_per_proof": ms_per_step, "steady_state_ms_per_proof": (steady["ms_per_proof"] if steady else None), "steady_state": steady,
+           "latency_ms_per_proof": (min(v["median_ms"] for v in latency.values() if isinstance(v, dict)) if latency else None), "latency": latency,
+           "per_rank_ms_per_proof": per_rank_ms, "collective_world_size": (dist.get_world_size() if world > 1 else 1),
+           "collective_backend": (dist.get_backend() if world > 1 else None), "rank_devices": rank_devices,
+           "host_enqueue_ms_per_step": t_enq * 1e3 / max(args.steps, 1), "aggregate_fr": hex(aggregate), "setup": wl.info, "roofline": roofline,
+           "roofline_chip_filling": roofline_fill, "roofline_all": roofline_all, "g1_model": g1_model, "kernels": kernels,
            "g1_msm_mops_commit": wl.info["commit_mops"]}
     if "msm_accum" in prof:
         g1_ms = sum(prof[k]["ms"] for k in prof if k.startswith("msm_") or k == "g1_canonicalise") / nprof
@@ -639,14 +822,23 @@ def main():
         out["g1_msm_mops"] = out["g1_msm_fullwidth"]["mops"]
     if world > 1:
         dist.barrier()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_baseline != "off":
-        out["cpu_baseline"] = cpu_baseline(zk, wl, args.cpu_baseline)
+    rc = 0
+    if want_cpu:
+        out["cpu_baseline"], checked = cpu_baseline(zk, wl, args.cpu_baseline, parity_src)
+        if checked is not None:
+            checked["gpu_configuration"] = "derive_rounds=%d, %d proofs in flight, sealed on the G1 streams (the timed region's configuration)" % (1 if derive else 0, len(wl.trs) if pipelined else 1)
+            out["parity_checked"] = checked
+            if not checked["ok"]:
+                rc = 4
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
     zk.close()
+    if rc:
+        sys.stderr.write("bench.py: the GPU transcript differs from the oracle's (parity_checked.mismatch)\n")
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,120 @@
+"""The BENCHMARKED configuration at full size: bench.py proves the 18M-parameter MLP at batch 256 with
+derived round commitments (`derive_rounds` = 1: T_r from the folding relation behind the MSM batch), four transcripts in flight and
+sealed G1 phases on two G1 streams -- k_lo = 11, 2048 generators, 121 derived products per layer.  These tests pin exactly that
+configuration:
+
+  * every proof made that way equals, value for value, the proof made with the library defaults (every T_r an MSM) synchronously;
+  * the verifier accepts a derived, pipelined proof made with hash-derived challenges;
+  * the CPU oracle (the restatement of the reference algorithm, zkfc.cu:128-145 / zkrelu.cu:79-100 / commitment.cu:43-92), run on the
+    same activations, weights, generators, commitments and challenges, returns the same Fr values bit for bit and the same G1 points
+    (affine-canonical) for zkFC 7, zkFC 6 and zkReLU 6 at batch 256 -- through the very function bench.py's cpu_baseline leg uses
+    for its `parity_checked` object.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.gpu
+
+
+def eq(a, b):
+    return np.array_equal(np.asarray(a), np.asarray(b))
+
+
+@pytest.fixture(scope="module")
+def zk():
+    from zkdl_amd.capi import MSM_PIPPENGER, Zk
+    z = Zk(0)
+    z.set_msm_mode(MSM_PIPPENGER)
+    yield z
+    z.close()
+
+
+@pytest.fixture(scope="module")
+def wl(zk):
+    import bench
+    dims, batch = bench.WORKLOADS["mlp18m_b256"]
+    return bench.Workload(zk, dims, batch, seed=11, inflight=4)
+
+
+def pipelined_proofs(zk, wl, steps, derive):
+    """`steps` proofs enqueued back to back on the rotating transcripts and sealed (bench.py's timed loop); returns each proof's
+    (Fr, affine G1, infinity flags, digest lanes) read after ALL of them have been submitted."""
+    from zkdl_amd.dist import lanes_to_fr
+    assert len(steps) <= len(wl.trs)
+    zk.set_flag("derive_rounds", 1 if derive else 0)
+    rows = zk.empty(2 * len(steps), 8)                       # 8 x uint64 per proof
+    for j, st in enumerate(steps):
+        tr = wl.trs[j]
+        wl.prove(wl.challenges(st), tr)
+        tr.seal(rows.ptr + 64 * j)
+    out = []
+    for j, st in enumerate(steps):
+        fr, _ = wl.trs[j].read()
+        aff, inf = wl.trs[j].read_affine()
+        out.append((fr, aff, inf))
+    zk.sync()
+    lanes = rows.download().reshape(-1).view(np.uint64).reshape(len(steps), 8)
+    zk.set_flag("derive_rounds", 0)
+    return out, [lanes_to_fr([int(x) for x in row]) for row in lanes]
+
+
+def test_derived_pipelined_proofs_equal_the_default_synchronous_ones(zk, wl):
+    from zkdl_amd.capi import Transcript
+    steps = [0, 1, 2, 3]
+    got, digests = pipelined_proofs(zk, wl, steps, derive=True)
+    zk.set_flag("derive_rounds", 0)
+    tr = Transcript(zk)
+    for j, st in enumerate(steps):
+        wl.prove(wl.challenges(st), tr)                      # library defaults: every T_r an MSM, flushed on the main stream
+        fr, _ = tr.read()
+        aff, inf = tr.read_affine()
+        d = int.from_bytes(np.ascontiguousarray(tr.digest()).tobytes(), "little")
+        assert eq(fr, got[j][0]), ("Fr transcript", st)
+        assert eq(aff, got[j][1]) and eq(inf, got[j][2]), ("G1 transcript", st)
+        assert d == digests[j], ("digest", st)
+    tr.close()
+    # k_lo = 11 layers exist in this model: 121 derived products each
+    assert max(s["n_gens"] for s in wl.shapes) == 2048
+
+
+def test_verifier_accepts_a_derived_pipelined_proof(zk, wl):
+    from zkdl_amd.proof import fs_challenges, statement_digest, verify_mlp
+    coms = [fc.com() for fc in wl.fcs]
+    chal = fs_challenges(statement_digest(zk, wl.dims, wl.batch, wl.gens, coms, wl.X, wl.Yhat), wl.dims, wl.batch)
+    zk.set_flag("derive_rounds", 1)
+    # three other proofs in flight around it
+    for j in range(3):
+        wl.prove(wl.challenges(100 + j), wl.trs[j])
+        wl.trs[j].seal()
+    wl.prove(chal, wl.trs[3])
+    wl.trs[3].seal()
+    blob = wl.trs[3].serialize()
+    zk.set_flag("derive_rounds", 0)
+    ok, msg, _ = verify_mlp(zk, wl.dims, wl.batch, wl.gens, coms, wl.X, wl.Yhat, blob)
+    assert ok, msg
+    bad = bytearray(blob)
+    bad[24 + 32 * 7 + 3] ^= 2
+    assert not verify_mlp(zk, wl.dims, wl.batch, wl.gens, coms, wl.X, wl.Yhat, bytes(bad), chal=chal)[0]
+
+
+def test_oracle_matches_the_benchmarked_configuration_at_batch_256(zk, wl):
+    import bench
+    got, _ = pipelined_proofs(zk, wl, [7, 8, 9, 10], derive=True)
+    fr, aff, inf = got[2]
+    base, checked = bench.cpu_baseline(zk, wl, "sample", (wl.challenges(9), fr, aff, inf))
+    assert checked["ok"], checked
+    assert checked["calls"] == ["zkFC7", "zkFC6", "zkReLU6"]
+    assert checked["g1"] == 2 * (3 * 11 + 2) and checked["fr"] > 300
+    assert base["kind"] == "port" and base["cores"] >= 1
+    # and a corrupted GPU value is reported, not swallowed
+    fr2 = fr.copy()
+    fr2[0, 0] ^= 1
+    _, bad = bench.cpu_baseline_check_only(zk, wl, [("fc", len(wl.shapes) - 1)], (wl.challenges(9), fr2, aff, inf))
+    assert not bad["ok"] and bad["mismatch"] == ["zkFC7"]

@@ -156,3 +156,43 @@ def test_demo_accepts_linear_layers_with_bias(tmp_path, oracle):
     A, *_ = oracle.relu_forward(oracle.fc_forward(X, Wq[0], 4, 8, 8))
     Y = oracle.fr_unmont(oracle.fc_forward(A, Wq[1], 4, 8, 4))
     assert vals == [bm.limbs_to_int(r) for r in Y]
+
+
+def test_demo_driver_at_the_headline_configuration(tmp_path):
+    """The reference's actual driver surface at BASELINE configs[2]: `python -m zkdl_amd.model` with its defaults
+    (model.py:14-51: 784-1000-1773x5-1124-1000, batch 256) -> `./demo traced_model.pt sample_input.pt` (demo.cu:99-142),
+    then again with --fs --verify.  demo.out (Y_hat un-Montgomery'd, 256 x 1024 padded entries) de-quantises to the float
+    model's output on the un-padded 256 x 1000 block, the parameter count line is the reference's, the proof verifies, and
+    the printed "Proof time ... per data point" lines are kept (gpurun_out/demo_headline.txt when that directory exists)."""
+    exe = os.path.join(HOST, "demo")
+    if not os.path.exists(exe):
+        pytest.skip("zkdl_amd/host/demo not built (needs LibTorch)")
+    import re
+    import torch
+    import bigint_model as bm
+    d = str(tmp_path)
+    subprocess.run([sys.executable, "-m", "zkdl_amd.model", "--out-dir", d], check=True, cwd=ROOT)
+    model_pt, input_pt = os.path.join(d, "traced_model.pt"), os.path.join(d, "sample_input.pt")
+    run = subprocess.run([exe, model_pt, input_pt, "--seed", "5", "--repeat", "3"], capture_output=True, text=True, cwd=d, timeout=900)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "Total number of parameters: 18247968" in run.stdout
+    cold = float(re.search(r"Proof time: ([0-9.eE+-]+) seconds per data point", run.stdout).group(1))
+    warm = float(re.search(r"Warm proof time: ([0-9.eE+-]+) seconds per data point", run.stdout).group(1))
+    assert 0 < warm <= cold < 0.1                                   # north_star: <= 0.1 s per example at batch 256
+    vals = [int(x, 16) for x in open(os.path.join(d, "demo.out")).read().strip().strip("[]").split("\n")]
+    assert len(vals) == 256 * 1024
+    m = torch.jit.load(model_pt)
+    x = list(torch.jit.load(input_pt).parameters())[0].detach()
+    with torch.no_grad():
+        want = m(x).double().numpy()
+    got = np.array([(v - bm.R_MOD if v > bm.R_MOD // 2 else v) / 2.0 ** 32 for v in vals]).reshape(256, 1024)
+    assert np.abs(got[:, :1000] - want).max() < 2e-3
+    assert np.all(got[:, 1000:] == 0)                               # padded output columns
+    run2 = subprocess.run([exe, model_pt, input_pt, "--fs", "--verify", "--repeat", "1"], capture_output=True, text=True, cwd=d, timeout=900)
+    assert run2.returncode == 0, run2.stdout + run2.stderr
+    assert "Verification: OK" in run2.stdout and "Total number of parameters: 18247968" in run2.stdout
+    keep = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(keep):
+        with open(os.path.join(keep, "demo_headline.txt"), "w") as f:
+            f.write("$ python -m zkdl_amd.model && ./demo traced_model.pt sample_input.pt --seed 5 --repeat 3\n" + run.stdout)
+            f.write("\n$ ./demo traced_model.pt sample_input.pt --fs --verify --repeat 1\n" + run2.stdout)

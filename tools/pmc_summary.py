@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 --pmc counter_collection CSVs (one row per dispatch and counter) into one JSON:
 per kernel, the number of dispatches seen and the AVERAGE value per launch of every counter, plus the derived
-figures bench.py and DESIGN.md quote.  usage: pmc_summary.py <dir with pmc_*/ subdirs> [out_json]
+figures bench.py and DESIGN.md quote.  usage: pmc_summary.py <dir with pmc_*/ subdirs> [out_json] [commit the library was built from]
 
 Derived (gfx950: SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count quad-cycles, GRBM_GUI_ACTIVE is summed over
 the 8 XCDs -- MI355X_MICROARCH.md, rocprofv3 PMC slots):
@@ -19,7 +19,8 @@ import sys
 
 def main():
     root = sys.argv[1]
-    out_path = sys.argv[2] if len(sys.argv) > 2 else "profiles/pmc_r02.json"
+    out_path = sys.argv[2] if len(sys.argv) > 2 else "profiles/pmc_r03.json"
+    commit = sys.argv[3] if len(sys.argv) > 3 else "unknown"
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
     for path in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
@@ -46,7 +47,7 @@ def main():
             rec["valu_active_per_busy_cycle"] = rec.get("SQ_ACTIVE_INST_VALU", 0.0) / rec["SQ_BUSY_CYCLES"]
         kernels[k] = rec
     json.dump({"source": "rocprofv3 --pmc passes of `bench.py --serial --steps 2 --warmup 1` (tools/collect_profiles.sh), averaged per launch",
-               "kernels": kernels}, open(out_path, "w"), indent=1, sort_keys=True)
+               "commit": commit, "kernels": kernels}, open(out_path, "w"), indent=1, sort_keys=True)
     print("wrote", out_path, len(kernels), "kernels")
 
 

@@ -231,6 +231,14 @@ namespace zk {
       return (ctx)->fail(ZK_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));      \
   } while (0)
 
+// Timing-experiment switches (skip the recorded Fr work, the MSM batch or the derived round commitments: the transcript is then
+// garbage) exist only in builds made with `make EXPERIMENTS=1` (-DZKDL_EXPERIMENTS); the shipping library ignores the variables.
+#ifdef ZKDL_EXPERIMENTS
+inline bool experiment_on(const char* name) { return getenv(name) != nullptr; }
+#else
+constexpr bool experiment_on(const char*) { return false; }
+#endif
+
 #define ZK_TRY(expr)              \
   do {                            \
     int _rc = (expr);             \

@@ -304,8 +304,11 @@ int zk_transcript::seal_pair(zk_transcript* other, uint64_t* out8_d, uint64_t* o
   ZK_TRY(rec_merge(ctx, &rec, &other->rec));
   ZK_TRY(rec_execute(ctx, &rec, /*join=*/!ctx->pipeline_fr));
   ZK_TRY(rec_execute(ctx, &other->rec, /*join=*/!ctx->pipeline_fr));  // only when there was nothing to merge into
-  ZK_TRY(g1_phase(out8_d));
-  return other->g1_phase(other_out8_d);
+  // both G1 phases are always submitted: a failure of the first must not leave `other` with its Fr phase executed, its MSM queue
+  // intact and no seal (the first error is what the caller sees; a failed transcript must be reset before reuse)
+  const int rc = g1_phase(out8_d);
+  const int rc2 = other->g1_phase(other_out8_d);
+  return rc != ZK_OK ? rc : rc2;
 }
 
 int zk_transcript::g1_phase(uint64_t* out8_d) {
@@ -319,7 +322,7 @@ int zk_transcript::g1_phase(uint64_t* out8_d) {
   ctx->stream = g.stream;
   ctx->cur_pool = &g.pool;
   int rc = ZK_OK;
-  static const bool skip_g1 = getenv("ZKDL_EXPERIMENT_SKIP_G1") != nullptr;  // timing experiments only: the G1 values are garbage then
+  static const bool skip_g1 = experiment_on("ZKDL_EXPERIMENT_SKIP_G1");  // timing experiments only: the G1 values are garbage then
   if (!queue.jobs.empty() && !skip_g1) rc = msm_run_jobs(ctx, queue.jobs, queue.c);
   // the latency-bound tail (derived round commitments, canonicalisation, digest) moves to a tail stream when there is one
   zk_ctx::Lane* tail = ctx->tail_lanes.empty() ? nullptr : &ctx->tail_lanes[ctx->next_tail++ % ctx->tail_lanes.size()];

@@ -960,7 +960,7 @@ __global__ void __launch_bounds__(64) k_derive_sum(const DeriveJob* __restrict__
 }
 int msm_run_derives(zk_ctx* ctx, const std::vector<DeriveJobHost>& derives) {
   if (derives.empty()) return ZK_OK;
-  static const bool skip = getenv("ZKDL_EXPERIMENT_SKIP_DERIVE") != nullptr;  // timing experiments only: T_1.. stay unset
+  static const bool skip = experiment_on("ZKDL_EXPERIMENT_SKIP_DERIVE");  // timing experiments only: T_1.. stay unset
   if (skip) return ZK_OK;
   std::vector<DeriveJob> jobs;
   std::vector<uint32_t> seg;

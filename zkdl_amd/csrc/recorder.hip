@@ -176,7 +176,7 @@ int rec_execute(zk_ctx* ctx, Recorder* r, bool join) {
     }
   }
   auto stream_of = [&](uint32_t g) -> hipStream_t { return (g == 0 || !fan_out) ? home : ctx->lanes[(g - 1) % ctx->lanes.size()].stream; };
-  static const bool skip_fr = getenv("ZKDL_EXPERIMENT_SKIP_FR") != nullptr;  // timing experiments only: nothing recorded is launched
+  static const bool skip_fr = experiment_on("ZKDL_EXPERIMENT_SKIP_FR");  // timing experiments only: nothing recorded is launched
   for (size_t i = 0; i < batches.size() && rc == ZK_OK && !skip_fr; i++) {
     const Batch& b = batches[i];
     ctx->stream = stream_of(b.group);
@@ -219,19 +219,22 @@ int rec_execute(zk_ctx* ctx, Recorder* r, bool join) {
 int rec_merge(zk_ctx* ctx, Recorder* dst, Recorder* src) {
   if (src->chains.empty()) return ZK_OK;
   if (dst->chains.empty()) return ZK_OK;  // nothing to zip with: the caller executes src on its own
+  // upload src's blob FIRST: if staging fails nothing has been spliced and both recorders are as they were
+  {
+    const size_t total = src->blob.size(), step = 1u << 20;
+    for (size_t o = 0; o < total; o += step) {
+      size_t nb = std::min(step, total - o);
+      void* st = ctx->stage_put(src->blob.data() + o, nb);
+      if (!st) return ctx->fail(ZK_ERR_ALLOC, "pinned staging exhausted");
+      ZK_TRY(dev_copy(ctx, src->blob_dev + o, st, (nb + 15) & ~(size_t)15));
+    }
+  }
   const size_t base = dst->args.size();
   dst->args.insert(dst->args.end(), src->args.begin(), src->args.end());
   for (auto& c : src->chains) {
     for (auto& op : c.ops)
       if (op.k) op.args_off += base;
     dst->chains.push_back(std::move(c));
-  }
-  int rc = ZK_OK;
-  const size_t total = src->blob.size(), step = 1u << 20;
-  for (size_t o = 0; o < total && rc == ZK_OK; o += step) {
-    size_t nb = std::min(step, total - o);
-    void* st = ctx->stage_put(src->blob.data() + o, nb);
-    rc = st ? dev_copy(ctx, src->blob_dev + o, st, (nb + 15) & ~(size_t)15) : ctx->fail(ZK_ERR_ALLOC, "pinned staging exhausted");
   }
   if (src->blob_dev) dst->deferred_free.push_back(src->blob_dev);
   for (void* p : src->deferred_free) dst->deferred_free.push_back(p);
@@ -242,7 +245,7 @@ int rec_merge(zk_ctx* ctx, Recorder* dst, Recorder* src) {
   src->blob.clear();
   auto it = std::find(ctx->pending_recs.begin(), ctx->pending_recs.end(), src);
   if (it != ctx->pending_recs.end()) ctx->pending_recs.erase(it);
-  return rc;
+  return ZK_OK;
 }
 
 void rec_release_held(zk_ctx* ctx, Recorder* r) {

@@ -123,6 +123,18 @@ bool same_point(const G1J& j, const G1A& a, bool a_inf) {
   const Fp z2 = fp_sqr(j.z);
   return l_eq(j.x, fp_mul(a.x, z2)) && l_eq(j.y, fp_mul(a.y, fp_mul(z2, j.z)));
 }
+// A prover-supplied affine point must be a canonical encoding of a curve point: both coordinates below p and y^2 = x^3 + 4
+// (Montgomery form; the a = 0 group law never reads b, so an off-curve point would be processed silently otherwise).
+// Infinity is encoded as all-zero coordinates + flag.  Membership in the prime-order subgroup is checked by the caller ([r] P = O).
+bool valid_encoding(const G1A& a, bool inf) {
+  if (inf) return l_is_zero(a.x) && l_is_zero(a.y);
+  Fp pm;
+  for (int i = 0; i < 12; i++) pm.v[i] = FpP::P(i);
+  if (l_gte(a.x, pm) || l_gte(a.y, pm)) return false;
+  Fp four = fp_one();
+  four = fp_dbl(fp_dbl(four));
+  return l_eq(fp_sqr(a.y), fp_add(fp_mul(fp_sqr(a.x), a.x), four));
+}
 G1J from_affine(const G1A& a, bool inf) {
   G1J r = g1_zero();
   if (!inf) {
@@ -159,8 +171,11 @@ int verify_opening(zk_ctx* ctx, const Fail& fail, zk_gens* gens, const zk_g1j* c
   // the 3 k_lo + 2 scalar multiplications of the folding relation, as one batched launch of the literal kernel:
   //   [R] com_eval | per round: u(1-u) T_r, (1-u)^2 T0_r, u^2 T1_r | t(0) g_final      (scalars = raw integers)
   const size_t nmul = 3 * (size_t)k_lo + 2;
-  std::vector<G1J> pts(nmul);
-  std::vector<Fr> sc(nmul);
+  for (size_t i = 0; i < nmul; i++)
+    if (!valid_encoding(lda(&g1_h[i]), inf_h[i] != 0)) return fail("transcript point " + std::to_string(i) + " is not a canonical encoding of a point on y^2 = x^3 + 4");
+  // the second half of the batch is [r] P for every transcript point: all must be the identity (prime-order subgroup)
+  std::vector<G1J> pts(2 * nmul);
+  std::vector<Fr> sc(2 * nmul);
   auto tp = [&](size_t i) { return from_affine(lda(&g1_h[i]), inf_h[i] != 0); };
   pts[0] = tp(0);
   sc[0] = fr_one();  // raw limbs of the Montgomery one = R mod r
@@ -176,16 +191,26 @@ int verify_opening(zk_ctx* ctx, const Fail& fail, zk_gens* gens, const zk_g1j* c
   }
   pts[nmul - 1] = tp(3 * (size_t)k_lo + 1);
   sc[nmul - 1] = t0;  // me_open multiplies by the RAW limbs of the (Montgomery-form) scalars (commitment.cu:57-59)
-  ZK_ALLOC(ctx, pd, G1J, nmul);
-  ZK_ALLOC(ctx, sd, Fr, nmul);
-  ZK_ALLOC(ctx, od, G1J, nmul);
-  ZK_TRY(host_to_dev(ctx, pd.get(), pts.data(), nmul * sizeof(G1J)));
-  ZK_TRY(host_to_dev(ctx, sd.get(), sc.data(), nmul * sizeof(Fr)));
-  ZK_TRY(g1_mul_dev(ctx, pd.get(), (uint32_t)nmul, sd.get(), (uint32_t)nmul, od.get()));
-  std::vector<G1J> prod(nmul);
+  {
+    Fr rmod;
+    for (int i = 0; i < 8; i++) rmod.v[i] = FrP::P(i);  // the scalar multiplication runs on raw limbs (g1-tensor.cu:422-430): k = r is fine
+    for (size_t i = 0; i < nmul; i++) {
+      pts[nmul + i] = tp(i);
+      sc[nmul + i] = rmod;
+    }
+  }
+  ZK_ALLOC(ctx, pd, G1J, 2 * nmul);
+  ZK_ALLOC(ctx, sd, Fr, 2 * nmul);
+  ZK_ALLOC(ctx, od, G1J, 2 * nmul);
+  ZK_TRY(host_to_dev(ctx, pd.get(), pts.data(), 2 * nmul * sizeof(G1J)));
+  ZK_TRY(host_to_dev(ctx, sd.get(), sc.data(), 2 * nmul * sizeof(Fr)));
+  ZK_TRY(g1_mul_dev(ctx, pd.get(), (uint32_t)(2 * nmul), sd.get(), (uint32_t)(2 * nmul), od.get()));
+  std::vector<G1J> prod(2 * nmul);
   G1J ev[2];
-  ZK_TRY(dev_to_host(ctx, prod.data(), od.get(), nmul * sizeof(G1J)));
+  ZK_TRY(dev_to_host(ctx, prod.data(), od.get(), 2 * nmul * sizeof(G1J)));
   ZK_TRY(dev_to_host(ctx, ev, evals.get(), sizeof ev));
+  for (size_t i = 0; i < nmul; i++)
+    if (!l_is_zero(prod[nmul + i].z)) return fail("transcript point " + std::to_string(i) + " is not in the prime-order subgroup ([r] P != O)");
   if (!same_point(ev[0], lda(&g1_h[0]), inf_h[0] != 0)) return fail("com(u_hi) is not the multilinear evaluation of the commitment");
   if (!same_point(ev[1], lda(&g1_h[3 * (size_t)k_lo + 1]), inf_h[3 * (size_t)k_lo + 1] != 0))
     return fail("the final generator is not the multilinear evaluation of the generators");
@@ -258,7 +283,7 @@ int zk_verify_fc(zk_ctx* ctx, zk_gens* gens, const zk_g1j* com_d, uint32_t m, ui
   const uint32_t k_bs = ceil_log2(batch), k_in = ceil_log2(in), k_out = ceil_log2(out), k_lo = ceil_log2(n_gens), k_hi = ceil_log2(m);
   if (in == 0 || out == 0 || batch == 0 || m == 0 || n_gens == 0 || (uint64_t)in * out != (uint64_t)m * n_gens || k_in + k_out != k_lo + k_hi)
     return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
-  if (n_fr != 3 * (size_t)k_in + 4 || n_g1 != 3 * (size_t)k_lo + 2) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
+  if (n_fr != 3 * (size_t)k_in + 4 || n_g1 != 3 * (size_t)k_lo + 2 || n_gens != (1u << k_lo)) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   if ((k_bs && !u_bs_h) || (k_in && !u_in_h) || (k_out && !u_out_h)) return ctx->fail(ZK_ERR_ARG, "zk_verify_fc: null challenge vector");
   Fail fail{ctx, ok};
   (void)k_bs;

@@ -1,5 +1,5 @@
 // zkdl_amd/host/demo.cpp -- the reference driver (demo.cu) on the MI355X library.
-//   ./demo traced_model.pt sample_input.pt [--seed S] [--dump DIR] [--fs] [--verify]
+//   ./demo traced_model.pt sample_input.pt [--seed S] [--dump DIR] [--fs] [--verify] [--repeat N]
 // Same CLI, same inputs (TorchScript nn.Sequential of bias-free Linear + ReLU; a tensor saved as
 // parameter "0" of a scripted empty module, model.py:4-8), same outputs: demo.out (Y_hat, one
 // 0x%064x per line, demo.cu:119-122) and the three stdout lines (demo.cu:92,140-141).
@@ -10,9 +10,12 @@
 // --fs derives the challenges of every prove call from SHA-256(model file | input file | commitments) (zk_fs_derive) instead of
 // the seeded generator; --verify then checks the serialised proof call by call with zk_verify_fc / zk_verify_relu, reading
 // only public data (generators, commitments, the input and output tensors), and prints "Verification: OK" or the failed check.
+// --repeat N proves the same statement N more times after the reference's single (cold: first-use allocations, window tables)
+// timed loop and prints the best of them as "Warm proof time: ..." -- the transcript kept is the first run's.
 #include <torch/script.h>
 #include <torch/torch.h>
 
+#include <algorithm>
 #include <cstring>
 #include <fstream>
 #include <iterator>
@@ -115,7 +118,9 @@ int main(int argc, char* argv[]) {
   string dump_dir;
   vector<Fr_t> challenges;
   bool use_fs = false, do_verify = false;
+  int repeat = 0;
   for (int i = 3; i < argc; i++) {
+    if (string(argv[i]) == "--repeat" && i + 1 < argc) repeat = atoi(argv[i + 1]);
     if (string(argv[i]) == "--seed" && i + 1 < argc) zkdl::seed(strtoull(argv[i + 1], nullptr, 0));
     if (string(argv[i]) == "--dump" && i + 1 < argc) dump_dir = argv[i + 1];
     if (string(argv[i]) == "--fs") use_fs = true;
@@ -160,20 +165,23 @@ int main(int argc, char* argv[]) {
     zk_sha256(st.data(), st.size(), d);
     zkdl::fs_begin(d);
   }
+  auto prove_all = [&]() {   // demo.cu:124-138
+    if (use_fs) zkdl::fs_call(num_layer - 1, 0);
+    fcs[num_layer - 1].prove(A_vec[num_layer - 2], Y_hat, *generators[num_layer - 1]);
+    for (int i = num_layer - 2; i >= 0; --i) {
+      if (use_fs) zkdl::fs_call(i, 1);
+      relus[i].prove(Z_vec[i], A_vec[i]);
+      FrTensor& A_ = (i > 0) ? A_vec[i - 1] : X;
+      if (use_fs) zkdl::fs_call(i, 0);
+      fcs[i].prove(A_, Z_vec[i], *generators[i]);
+    }
+    zk_transcript_flush(zkdl::transcript());   // the deferred MSM batch belongs to the timed region
+    zk_ctx_sync(zkdl::ctx());
+  };
   Timer timer;
   zk_ctx_sync(zkdl::ctx());
   timer.start();
-  if (use_fs) zkdl::fs_call(num_layer - 1, 0);
-  fcs[num_layer - 1].prove(A_vec[num_layer - 2], Y_hat, *generators[num_layer - 1]);
-  for (int i = num_layer - 2; i >= 0; --i) {
-    if (use_fs) zkdl::fs_call(i, 1);
-    relus[i].prove(Z_vec[i], A_vec[i]);
-    FrTensor& A_ = (i > 0) ? A_vec[i - 1] : X;
-    if (use_fs) zkdl::fs_call(i, 0);
-    fcs[i].prove(A_, Z_vec[i], *generators[i]);
-  }
-  zk_transcript_flush(zkdl::transcript());   // the deferred MSM batch belongs to the timed region
-  zk_ctx_sync(zkdl::ctx());
+  prove_all();
   timer.stop();
 
   size_t n_fr = 0, n_g1 = 0;
@@ -183,11 +191,38 @@ int main(int argc, char* argv[]) {
   cout << "Proof time: " << timer.getTotalTime() / batch_size << " seconds per data point." << endl;
   cout << "Current HIP status: " << 0 << endl;
   cout << "Transcript: " << n_fr << " Fr + " << n_g1 << " G1 values, digest " << digest << endl;
-  if (do_verify) {  // the verifier's pass: public data + the serialised proof only
+  // serialised now: --repeat proves again into the same transcript object
+  vector<unsigned char> first_blob;
+  if (do_verify || !dump_dir.empty()) {
     size_t len = 0;
     zk_transcript_serialize(zkdl::transcript(), nullptr, 0, &len);
-    vector<unsigned char> buf(len);
-    zkdl::check(zk_transcript_serialize(zkdl::transcript(), buf.data(), buf.size(), &len));
+    first_blob.resize(len);
+    zkdl::check(zk_transcript_serialize(zkdl::transcript(), first_blob.data(), first_blob.size(), &len));
+  }
+  const vector<Fr_t> first_challenges = challenges;
+  if (repeat > 0) {
+    double best = 1e30;
+    for (int it = 0; it < repeat; it++) {
+      zk_transcript_reset(zkdl::transcript());
+      challenges.clear();
+      Timer t2;
+      zk_ctx_sync(zkdl::ctx());
+      t2.start();
+      prove_all();
+      t2.stop();
+      best = std::min(best, t2.getTotalTime());
+    }
+    Fr_t d2;
+    zk_transcript_digest(zkdl::transcript(), &d2);
+    cout << "Warm proof time: " << best / batch_size << " seconds per data point (best of " << repeat << "; " << best * 1e3 << " ms per batch-" << batch_size << " proof)" << endl;
+    if (use_fs && memcmp(&d2, &digest, sizeof digest) != 0) {   // hash-derived challenges: the same statement must give the same proof
+      cout << "Repeat: transcript digest differs from the first run" << endl;
+      return 1;
+    }
+    challenges = first_challenges;
+  }
+  if (do_verify) {  // the verifier's pass: public data + the serialised proof only
+    const vector<unsigned char>& buf = first_blob;
     vector<Fr_t> fr(n_fr);
     vector<G1Affine_t> g1(n_g1);
     vector<uint8_t> inf(n_g1);
@@ -237,11 +272,7 @@ int main(int argc, char* argv[]) {
       put("gens_" + to_string(i) + ".bin", g.data(), g.size() * sizeof(G1Jacobian_t));
     }
     put("challenges.bin", challenges.data(), challenges.size() * sizeof(Fr_t));
-    size_t len = 0;
-    zk_transcript_serialize(zkdl::transcript(), nullptr, 0, &len);
-    vector<unsigned char> buf(len);
-    zkdl::check(zk_transcript_serialize(zkdl::transcript(), buf.data(), buf.size(), &len));
-    put("transcript.bin", buf.data(), len);
+    put("transcript.bin", first_blob.data(), first_blob.size());
   }
   return 0;
 }
