@@ -406,7 +406,10 @@ def main():
                     "they have no later proofs to hide the longer derived form under")
     ap.add_argument("--pair", type=int, default=1, choices=[1, 2], help="proofs submitted together (zk_transcript_seal_pair): 2 = the Fr phases of two consecutive "
                     "proofs share their launches; every proof is still its own batch-256 proof with its own transcript and digest row")
-    ap.add_argument("--inflight", type=int, default=4, help="transcripts rotated by the pipelined loop (proofs whose G1 phase may still be running)")
+    ap.add_argument("--g1-streams", type=int, default=-1, help="G1 streams sealed proofs rotate over (-1: one when --g1-batch > 1, else the library's two)")
+    ap.add_argument("--g1-batch", type=int, default=2, help="sealed proofs whose G1 phases (MSM batch, derived round commitments, canonical form) run as ONE batch: "
+                    "the latency-bound launches behind the accumulation are shared (zk_set_flag g1_batch); a proof then waits for its partners")
+    ap.add_argument("--inflight", type=int, default=6, help="transcripts rotated by the pipelined loop (proofs whose G1 phase may still be running)")
     ap.add_argument("--no-derive", action="store_true", help="run every round commitment T_r of the openings as an MSM (library default) instead of deriving T_1.. from the "
                     "folding relation behind the MSM batch (the throughput configuration: -31 %% msm_accum work, a ~6 ms longer G1 phase per proof)")
     ap.add_argument("--serial", action="store_true", help="no worker streams at all: every launch runs alone (the schedule the roofline durations are measured under)")
@@ -495,6 +498,9 @@ def main():
         zk.set_msm_window(args.msm_window)
     derive = not args.no_derive and args.msm == "pippenger"
     zk.set_flag("derive_rounds", 1 if derive else 0)
+    zk.set_flag("g1_batch", max(1, args.g1_batch))
+    g1_streams = args.g1_streams if args.g1_streams >= 0 else (1 if args.g1_batch > 1 else 0)
+    zk.set_flag("g1_streams", g1_streams)
     for kv in os.environ.get("ZKDL_BENCH_FLAGS", "").split(","):       # e.g. ZKDL_BENCH_FLAGS=derive_rounds=1,relu_bytes=0 (A/B runs)
         if "=" in kv:
             zk.set_flag(kv.split("=")[0], int(kv.split("=")[1]))
@@ -803,7 +809,7 @@ def main():
            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (Fr) / u32x12 (Fp) limbs",
            "data": "synthetic",
            "config": {"workload": args.workload, "dims": dims, "batch_per_gpu": batch, "parallelism": "independent proofs per rank, one RCCL all-reduce of the run aggregate",
-                      "msm": args.msm, "derive_rounds": bool(derive), "inflight": args.inflight, "proofs_per_submission": 2 if paired else 1, "prewarm_process": not args.no_prewarm,
+                      "msm": args.msm, "derive_rounds": bool(derive), "inflight": args.inflight, "g1_batch": args.g1_batch, "g1_streams": (g1_streams or 2), "proofs_per_submission": 2 if paired else 1, "prewarm_process": not args.no_prewarm,
                       "drain_form_proofs": (min(args.drain, args.steps) if derive else 0), "spinup_ms": args.spinup_ms, "spinup_proofs": n_spin,
                       "warmup_drain_form_proofs": (min(2, args.warmup) if derive and args.warmup >= 2 else 0),
                       "schedule_note": "the last drain_form_proofs proofs of the timed region run every round commitment as an MSM (derive_rounds off): they have no later proof to hide the derivation under"},

@@ -150,6 +150,12 @@ int zk_set_msm_window(zk_ctx* ctx, uint32_t window_bits);   /* 0 = automatic */
  *                   relation (k^2 - 1 scalar multiplications behind the MSM batch) instead of run as k - 1 full-size MSMs
  *   "batch_layers"  zk_fc_prove / zk_relu_prove record their launches; flush/seal runs them batched across layers
  *   "lanes"         worker streams (the recorder's groups, the G1 streams of zk_transcript_seal); off = one stream
+ *   "g1_batch"      (default 1) the G1 phases of that many consecutively sealed proofs run as ONE batch (one MSM batch, one derivation,
+ *                   one canonicalisation): the latency-bound launches behind the accumulation are shared; a sealed proof then waits for
+ *                   its partners (or for anyone touching its transcript, or zk_ctx_sync).  Throughput configuration of bench.py: 2.
+ *   "g1_streams"    (default 0 = all) how many of the context's G1 streams sealed proofs rotate over
+ *   "early_g1"      a sealed proof's G1 phase starts behind the openings' scalar preparation (all it needs) instead of behind the whole
+ *                   Fr phase; only the digest waits for the rest
  *   "weights_q16"   layers created while set keep an int16 copy of quantised weights (|w| < 2^15) for the
  *                   prover's two contractions of W and the integer forward pass */
 int zk_set_flag(zk_ctx* ctx, const char* name, int value);

@@ -65,10 +65,19 @@ def pipelined_proofs(zk, wl, steps, derive):
     return out, [lanes_to_fr([int(x) for x in row]) for row in lanes]
 
 
-def test_derived_pipelined_proofs_equal_the_default_synchronous_ones(zk, wl):
+@pytest.mark.parametrize("g1_batch,early_g1", [(1, 1), (1, 0), (2, 1), (3, 1), (4, 0)])
+def test_derived_pipelined_proofs_equal_the_default_synchronous_ones(zk, wl, g1_batch, early_g1):
+    """g1_batch: the G1 phases of that many sealed proofs run as one batch (3 leaves the fourth proof waiting for a partner until it
+    is read); early_g1: the G1 phase starts behind the openings' scalar preparation instead of behind the whole Fr phase."""
     from zkdl_amd.capi import Transcript
     steps = [0, 1, 2, 3]
-    got, digests = pipelined_proofs(zk, wl, steps, derive=True)
+    zk.set_flag("g1_batch", g1_batch)
+    zk.set_flag("early_g1", early_g1)
+    try:
+        got, digests = pipelined_proofs(zk, wl, steps, derive=True)
+    finally:
+        zk.set_flag("g1_batch", 1)
+        zk.set_flag("early_g1", 1)
     zk.set_flag("derive_rounds", 0)
     tr = Transcript(zk)
     for j, st in enumerate(steps):

@@ -128,7 +128,8 @@ int zk_ctx_create(int device, zk_ctx** out) {
   zk_ctx* ctx = new zk_ctx();
   ctx->device = device;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&ctx->t0) != hipSuccess ||
-      hipEventCreate(&ctx->t1) != hipSuccess || hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreate(&ctx->t1) != hipSuccess || hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->pre_ev, hipEventDisableTiming) != hipSuccess) {
     delete ctx;
     return ZK_ERR_DEVICE;
   }
@@ -221,6 +222,7 @@ int zk_ctx_create(int device, zk_ctx** out) {
 int zk_ctx_destroy(zk_ctx* ctx) {
   if (!ctx) return ZK_ERR_ARG;
   (void)hipSetDevice(ctx->device);
+  (void)ctx->flush_g1_pending();
   ctx->join_all();
   (void)hipDeviceSynchronize();
   ctx->prof_flush();
@@ -237,6 +239,7 @@ int zk_ctx_destroy(zk_ctx* ctx) {
     if (g.done) (void)hipEventDestroy(g.done);
   }
   (void)hipEventDestroy(ctx->fork_ev);
+  (void)hipEventDestroy(ctx->pre_ev);
   if (ctx->prof_base) (void)hipEventDestroy(ctx->prof_base);
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   (void)hipEventDestroy(ctx->t0);
@@ -251,6 +254,7 @@ int zk_ctx_destroy(zk_ctx* ctx) {
 }
 int zk_ctx_sync(zk_ctx* ctx) {
   CHECK_CTX(ctx);
+  ZK_TRY(ctx->flush_g1_pending());
   ctx->join_all();
   ZK_HIP(ctx, hipStreamSynchronize(ctx->main_stream));
   return ZK_OK;
@@ -599,6 +603,12 @@ int zk_set_flag(zk_ctx* ctx, const char* name, int value) {
   else if (!strcmp(name, "relu_bytes")) ctx->relu_bytes = value != 0;
   else if (!strcmp(name, "derive_rounds")) ctx->derive_rounds = value != 0;
   else if (!strcmp(name, "pipeline_fr")) ctx->pipeline_fr = value != 0;
+  else if (!strcmp(name, "early_g1")) ctx->early_g1 = value != 0;
+  else if (!strcmp(name, "g1_streams")) ctx->g1_active = value < 0 ? 0u : (uint32_t)value;
+  else if (!strcmp(name, "g1_batch")) {
+    ZK_TRY(ctx->flush_g1_pending());
+    ctx->g1_batch = value < 1 ? 1u : value > 8 ? 8u : (uint32_t)value;
+  }
   else if (!strcmp(name, "lanes")) ctx->lanes_enabled = value != 0;
   else if (!strcmp(name, "batch_layers")) ctx->batch_layers = value != 0;
   else if (!strcmp(name, "weights_q16")) ctx->flag_q16 = value != 0;

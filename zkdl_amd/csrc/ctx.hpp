@@ -167,6 +167,12 @@ struct zk_ctx {
   uint32_t next_tail = 0;
   hipStream_t main_stream = nullptr;
   hipEvent_t fork_ev = nullptr;
+  hipEvent_t pre_ev = nullptr;   // main stream at the start of a seal(): what the early-started G1 phase waits for besides the opening chains
+  bool early_g1 = true;          // sealed proofs: the G1 phase starts behind the opening's scalar preparation, not behind the whole Fr phase
+  uint32_t g1_batch = 1;         // sealed proofs whose G1 phases run as ONE batch (1: every proof on its own)
+  uint32_t g1_active = 0;        // G1 streams in use, round-robin (0 = all that were created); "g1_streams"
+  std::vector<zk_transcript*> g1_pending;  // sealed, Fr phase submitted, G1 phase waiting for partners
+  int flush_g1_pending();        // layers.hip
   uint32_t layer_serial = 0;  // next zk_fc / zk_relu serial number (their lane hint)
   bool lanes_enabled = true;
   // main stream waits for the worker lanes (NOT for the G1 stream: a sealed proof keeps running there

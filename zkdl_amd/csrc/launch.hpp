@@ -75,6 +75,8 @@ struct RecOp {
 };
 struct RecChain {
   uint32_t group = 0;  // chains of one group are zipped together and run on that group's stream
+  bool early = false;  // scheduled before the group's other chains; an event behind the last early launch lets a consumer start
+                       // before the rest of the Fr phase has run (the opening's scalar preparation: all the G1 phase needs)
   std::vector<RecOp> ops;
 };
 struct Recorder {
@@ -93,10 +95,13 @@ static constexpr size_t REC_BLOB_CAP = 8u << 20;
 enum { REC_GROUP_FC_A = 0, REC_GROUP_FC_OPEN = 1, REC_GROUP_RELU_MAG = 2, REC_GROUP_RELU_REM = 3 };
 
 int rec_begin_chain(zk_ctx* ctx, Recorder* r, uint32_t group = 0);  // sets ctx->rec; allocates the blob on first use
-void rec_split(zk_ctx* ctx, uint32_t group);              // recording: what follows is independent of what came before
+void rec_split(zk_ctx* ctx, uint32_t group, bool early = false);  // recording: what follows is independent of what came before
 void rec_end_chain(zk_ctx* ctx);                           // clears ctx->rec
 void rec_rollback(zk_ctx* ctx, Recorder* r, size_t keep_chains);  // a recording prove call failed: drop its chains
-int rec_execute(zk_ctx* ctx, Recorder* r, bool join = true);  // zip + launch on ctx->stream; join: home waits for the groups, temporaries released
+// zip + launch on ctx->stream; join: home waits for the groups, temporaries released.  early_out (optional): receives one event per
+// group that had early chains, recorded behind the last early launch on that group's stream (events from ctx->get_event(); the caller
+// returns them to ctx->event_pool once it has enqueued its waits)
+int rec_execute(zk_ctx* ctx, Recorder* r, bool join = true, std::vector<hipEvent_t>* early_out = nullptr);
 int rec_merge(zk_ctx* ctx, Recorder* dst, Recorder* src);  // src's chains join dst's: one execution zips both
 void rec_release_held(zk_ctx* ctx, Recorder* r);           // after an unjoined execution, once every group stream is known to be ordered before the caller
 void* rec_blob_put(zk_ctx* ctx, const void* src, size_t bytes);  // -> DEVICE address inside the blob

@@ -255,6 +255,7 @@ int zk_transcript::ensure(size_t add_fr, size_t add_g1) {
 
 void zk_transcript::unseal() {
   if (!sealed) return;
+  if (g1_deferred) (void)ctx->flush_g1_pending();  // its G1 phase was still waiting for partners
   (void)hipStreamWaitEvent(ctx->main_stream, sealed_ev, 0);
   sealed = false;
   deferred_keep.clear();  // owned by worker-lane pools; lanes fork from the main stream, i.e. behind this wait
@@ -276,6 +277,7 @@ int zk_transcript::flush() {
 // the main stream and on every dirty lane; the main stream does not wait for the G1 stream, so the next
 // proof's Fr phase (worker lanes) runs under this proof's MSM tail.  Scratch comes from the G1 stream's own
 // pool; the prepared scalars (worker-lane pools) are held until unseal().
+static int g1_phase_run(zk_ctx* ctx, const std::vector<zk_transcript*>& trs);
 int zk_transcript::seal(uint64_t* out8_d) {
   if (ctx->g1_lanes.empty() || !ctx->lanes_enabled || ctx->stream != ctx->main_stream) {
     sealed_stream = nullptr;
@@ -286,8 +288,30 @@ int zk_transcript::seal(uint64_t* out8_d) {
   // Fr phase on the main stream + group lanes; the G1 stream waits for it below.  With "pipeline_fr" the groups are NOT joined on
   // the main stream: the next proof's groups queue behind this proof's, stream by stream, so a short group no longer idles until
   // the longest one is done (the temporaries then stay with the recorder until unseal()).
-  ZK_TRY(rec_execute(ctx, &rec, /*join=*/!ctx->pipeline_fr));
-  return g1_phase(out8_d);
+  std::vector<hipEvent_t> early;
+  (void)hipEventRecord(ctx->pre_ev, ctx->main_stream);  // everything the main stream held before this proof's Fr phase (buffer moves of ensure())
+  int rc = rec_execute(ctx, &rec, /*join=*/!ctx->pipeline_fr, &early);
+  if (rc != ZK_OK) {
+    for (hipEvent_t e : early) ctx->event_pool.push_back(e);
+    return rc;
+  }
+  return submit_g1(out8_d, &early, !early.empty());
+}
+
+// after the Fr phase has been submitted: run the G1 phase now, or -- "g1_batch" > 1 -- leave it with the context until that many
+// sealed proofs are waiting (or until anyone needs this one).  The events are taken over.
+int zk_transcript::submit_g1(uint64_t* out8_d, const std::vector<hipEvent_t>* early, bool early_ok) {
+  pending_out8 = out8_d;
+  if (early) pending_early = *early;
+  else pending_early.clear();
+  pending_early_ok = early_ok;
+  if (ctx->g1_batch > 1) {
+    g1_deferred = true;
+    sealed = true;
+    ctx->g1_pending.push_back(this);
+    return ctx->g1_pending.size() >= ctx->g1_batch ? ctx->flush_g1_pending() : ZK_OK;
+  }
+  return g1_phase_run(ctx, {this});
 }
 
 // Two proofs recorded on two transcripts, submitted together: their Fr chains are zipped into the same launches (a proof's Fr phase
@@ -302,28 +326,86 @@ int zk_transcript::seal_pair(zk_transcript* other, uint64_t* out8_d, uint64_t* o
   unseal();
   other->unseal();
   ZK_TRY(rec_merge(ctx, &rec, &other->rec));
-  ZK_TRY(rec_execute(ctx, &rec, /*join=*/!ctx->pipeline_fr));
-  ZK_TRY(rec_execute(ctx, &other->rec, /*join=*/!ctx->pipeline_fr));  // only when there was nothing to merge into
+  (void)hipEventRecord(ctx->pre_ev, ctx->main_stream);
+  std::vector<hipEvent_t> early, early2;
+  int rce = rec_execute(ctx, &rec, /*join=*/!ctx->pipeline_fr, &early);
+  const bool merged = other->rec.chains.empty();
+  if (rce == ZK_OK) rce = rec_execute(ctx, &other->rec, /*join=*/!ctx->pipeline_fr, &early2);  // only when there was nothing to merge into
+  if (rce != ZK_OK) {
+    for (hipEvent_t e : early) ctx->event_pool.push_back(e);
+    for (hipEvent_t e : early2) ctx->event_pool.push_back(e);
+    return rce;
+  }
   // both G1 phases are always submitted: a failure of the first must not leave `other` with its Fr phase executed, its MSM queue
-  // intact and no seal (the first error is what the caller sees; a failed transcript must be reset before reuse)
-  const int rc = g1_phase(out8_d);
-  const int rc2 = other->g1_phase(other_out8_d);
+  // intact and no seal (the first error is what the caller sees; a failed transcript must be reset before reuse).
+  // Merged execution: the events behind the zipped opening chains cover both proofs; this transcript carries them.
+  const bool ok1 = !early.empty();
+  const bool same_batch = ctx->g1_batch > 1 && ctx->g1_pending.size() + 2 <= ctx->g1_batch;  // both land in one G1 batch: its waits cover both
+  const int rc = submit_g1(out8_d, &early, ok1);
+  const int rc2 = other->submit_g1(other_out8_d, &early2, merged ? (ok1 && same_batch) : !early2.empty());
   return rc != ZK_OK ? rc : rc2;
 }
 
-int zk_transcript::g1_phase(uint64_t* out8_d) {
-  zk_ctx::Lane& g = ctx->g1_lanes[ctx->next_g1++ % ctx->g1_lanes.size()];
-  sealed_stream = g.stream;
-  if (!sealed_ev && hipEventCreateWithFlags(&sealed_ev, hipEventDisableTiming) != hipSuccess) return ctx->fail(ZK_ERR_DEVICE, "hipEventCreate failed");
-  (void)hipEventRecord(ctx->fork_ev, ctx->main_stream);
-  (void)hipStreamWaitEvent(g.stream, ctx->fork_ev, 0);
-  for (auto& l : ctx->lanes)
-    if (l.dirty) (void)hipStreamWaitEvent(g.stream, l.done, 0);  // stays dirty: the main stream has not joined it
+// The G1 phase of one or several sealed proofs as ONE batch on a G1 stream: all their MSM jobs in one sort / accumulate / combine /
+// reduce sequence, all their derived round commitments in one launch pair, one canonicalisation, then a digest each.  The chip-filling
+// accumulation scales with the number of proofs; everything behind it is a handful of waves per proof running dependent chains of
+// field products for ~3 ms (standalone: combine 0.36, row/column sums 0.22, weighted sums 0.33, derivation 1.8, canonical form 0.5),
+// whose latency is the same for one proof or for several -- so batching N proofs divides that part of the chain by N ("g1_batch").
+//
+// pending_early (per transcript, optional): events behind the opening chains' scalar preparation (rec_execute).  The MSM batch depends
+// on nothing else of the Fr phase, so with them the G1 stream starts while the proofs' sumchecks are still running and only the digests
+// -- which read every Fr value -- wait for the whole Fr phase.  Without them (nothing recorded, immediate mode) the G1 stream waits for
+// the Fr phase first.
+static int g1_phase_run(zk_ctx* ctx, const std::vector<zk_transcript*>& trs) {
+  if (trs.empty()) return ZK_OK;
+  const size_t n_g1s = ctx->g1_active && ctx->g1_active < ctx->g1_lanes.size() ? ctx->g1_active : ctx->g1_lanes.size();
+  zk_ctx::Lane& g = ctx->g1_lanes[ctx->next_g1++ % n_g1s];
+  for (zk_transcript* t : trs) {
+    t->sealed_stream = g.stream;
+    if (!t->sealed_ev && hipEventCreateWithFlags(&t->sealed_ev, hipEventDisableTiming) != hipSuccess) return ctx->fail(ZK_ERR_DEVICE, "hipEventCreate failed");
+  }
+  auto wait_fr_phase = [&](hipStream_t st) {
+    (void)hipEventRecord(ctx->fork_ev, ctx->main_stream);
+    (void)hipStreamWaitEvent(st, ctx->fork_ev, 0);
+    for (auto& l : ctx->lanes)
+      if (l.dirty) (void)hipStreamWaitEvent(st, l.done, 0);  // stays dirty: the main stream has not joined it
+  };
+  bool early_start = ctx->early_g1;
+  for (zk_transcript* t : trs)
+    if (!t->pending_early_ok) early_start = false;
+  if (early_start) {
+    (void)hipStreamWaitEvent(g.stream, ctx->pre_ev, 0);  // recorded at the latest seal(): main-stream order covers the earlier ones
+    for (zk_transcript* t : trs)
+      for (hipEvent_t e : t->pending_early) (void)hipStreamWaitEvent(g.stream, e, 0);
+  } else {
+    wait_fr_phase(g.stream);
+  }
   ctx->stream = g.stream;
   ctx->cur_pool = &g.pool;
   int rc = ZK_OK;
   static const bool skip_g1 = experiment_on("ZKDL_EXPERIMENT_SKIP_G1");  // timing experiments only: the G1 values are garbage then
-  if (!queue.jobs.empty() && !skip_g1) rc = msm_run_jobs(ctx, queue.jobs, queue.c);
+  // one MSM batch: the jobs of every proof (they must share the window width; they do unless zk_set_msm_window changed in between)
+  uint32_t c = 0;
+  bool same_c = true;
+  size_t njobs = 0, nder = 0;
+  for (zk_transcript* t : trs) {
+    if (t->queue.jobs.empty()) continue;
+    if (c == 0) c = t->queue.c;
+    else if (t->queue.c != c) same_c = false;
+    njobs += t->queue.jobs.size();
+    nder += t->queue.derives.size();
+  }
+  if (!skip_g1 && njobs) {
+    if (same_c && trs.size() > 1) {
+      std::vector<MsmJobHost> jobs;
+      jobs.reserve(njobs);
+      for (zk_transcript* t : trs) jobs.insert(jobs.end(), t->queue.jobs.begin(), t->queue.jobs.end());
+      rc = msm_run_jobs(ctx, jobs, c);
+    } else {
+      for (zk_transcript* t : trs)
+        if (rc == ZK_OK && !t->queue.jobs.empty()) rc = msm_run_jobs(ctx, t->queue.jobs, t->queue.c);
+    }
+  }
   // the latency-bound tail (derived round commitments, canonicalisation, digest) moves to a tail stream when there is one
   zk_ctx::Lane* tail = ctx->tail_lanes.empty() ? nullptr : &ctx->tail_lanes[ctx->next_tail++ % ctx->tail_lanes.size()];
   hipStream_t fin = g.stream;
@@ -334,12 +416,34 @@ int zk_transcript::g1_phase(uint64_t* out8_d) {
     ctx->stream = tail->stream;
     ctx->cur_pool = &tail->pool;
     fin = tail->stream;
-    sealed_stream = tail->stream;
+    for (zk_transcript* t : trs) t->sealed_stream = tail->stream;
   }
-  if (rc == ZK_OK && !skip_g1) rc = msm_run_derives(ctx, queue.derives);
-  if (rc == ZK_OK && n_g1 > n_g1_final && ctx->msm_mode == ZK_MSM_PIPPENGER) rc = g1_canonicalise_dev(ctx, g1_d + n_g1_final, (uint32_t)(n_g1 - n_g1_final));
-  if (rc == ZK_OK && out8_d) rc = transcript_digest_dev(ctx, fr_d, n_fr, g1_d, n_g1, nullptr, out8_d);
-  (void)hipEventRecord(sealed_ev, fin);
+  if (rc == ZK_OK && !skip_g1 && nder) {
+    if (trs.size() > 1) {
+      std::vector<DeriveJobHost> derives;
+      derives.reserve(nder);
+      for (zk_transcript* t : trs) derives.insert(derives.end(), t->queue.derives.begin(), t->queue.derives.end());
+      rc = msm_run_derives(ctx, derives);
+    } else {
+      rc = msm_run_derives(ctx, trs[0]->queue.derives);
+    }
+  }
+  if (rc == ZK_OK && ctx->msm_mode == ZK_MSM_PIPPENGER) {
+    CanonRanges cr;
+    cr.cnt = 0;
+    for (zk_transcript* t : trs)
+      if (t->n_g1 > t->n_g1_final) {
+        cr.p[cr.cnt] = t->g1_d + t->n_g1_final;
+        cr.n[cr.cnt] = (uint32_t)(t->n_g1 - t->n_g1_final);
+        cr.cnt++;
+      }
+    if (cr.cnt == 1) rc = g1_canonicalise_dev(ctx, cr.p[0], cr.n[0]);
+    else if (cr.cnt > 1) rc = g1_canonicalise_multi_dev(ctx, cr);
+  }
+  if (early_start) wait_fr_phase(fin);  // the digests read every Fr value; unseal() (which waits for sealed_ev) must imply the Fr phase as well
+  for (zk_transcript* t : trs)
+    if (rc == ZK_OK && t->pending_out8) rc = transcript_digest_dev(ctx, t->fr_d, t->n_fr, t->g1_d, t->n_g1, nullptr, t->pending_out8);
+  for (zk_transcript* t : trs) (void)hipEventRecord(t->sealed_ev, fin);
   if (tail) {
     (void)hipEventRecord(tail->done, tail->stream);
     tail->dirty = true;
@@ -347,16 +451,39 @@ int zk_transcript::g1_phase(uint64_t* out8_d) {
     (void)hipEventRecord(g.done, g.stream);
     g.dirty = true;
   }
-  sealed = true;
   ctx->stream = ctx->main_stream;
   ctx->cur_pool = &ctx->main_pool;
-  n_g1_final = n_g1;
-  queue.jobs.clear();
-  queue.derives.clear();
-  queue.c = 0;
-  for (auto& b : queue.keep) deferred_keep.push_back(std::move(b));
-  queue.keep.clear();
+  for (zk_transcript* t : trs) {
+    t->sealed = true;
+    t->g1_deferred = false;
+    t->n_g1_final = t->n_g1;
+    t->queue.jobs.clear();
+    t->queue.derives.clear();
+    t->queue.c = 0;
+    for (auto& b : t->queue.keep) t->deferred_keep.push_back(std::move(b));
+    t->queue.keep.clear();
+    for (hipEvent_t e : t->pending_early) ctx->event_pool.push_back(e);
+    t->pending_early.clear();
+    t->pending_early_ok = false;
+    t->pending_out8 = nullptr;
+  }
   return rc;
+}
+
+int zk_transcript::g1_phase(uint64_t* out8_d, const std::vector<hipEvent_t>* early) {
+  pending_out8 = out8_d;
+  if (early) pending_early = *early;
+  else pending_early.clear();
+  pending_early_ok = early && !early->empty();
+  return g1_phase_run(ctx, {this});
+}
+
+// sealed proofs whose G1 phase is waiting for partners ("g1_batch" > 1): run them now, as one batch
+int zk_ctx::flush_g1_pending() {
+  if (g1_pending.empty()) return ZK_OK;
+  std::vector<zk_transcript*> list;
+  list.swap(g1_pending);
+  return g1_phase_run(this, list);
 }
 
 // ------------------------------------------------------------------ zkFC
@@ -508,7 +635,7 @@ static int fc_prove_body(zk_ctx* ctx, zk_fc* fc, const Fr* x, uint32_t xn, const
   rec_split(ctx, REC_GROUP_FC_A);
   ZK_TRY(fr_me_dev(ctx, z, zn, uz.get(), k_out + k_bs, fr_slot + 3 * k_in + 2));
   // generators.open(weights, com, u_out || u_in)
-  rec_split(ctx, REC_GROUP_FC_OPEN);
+  rec_split(ctx, REC_GROUP_FC_OPEN, /*early=*/true);  // all the G1 phase needs from the Fr phase: it may start behind these launches
   ZK_TRY(open_dev(ctx, gens, fc->weights, wn, fc->com, u_out, k_out + k_in, g1_slot, g1_slot + 1, fr_slot + 3 * k_in + 3, &tr->queue, fc->wq));
   return ZK_OK;
 }

@@ -79,10 +79,15 @@ struct zk_transcript {  // proof values in the order of SURVEY.md App. A.6, resi
   bool sealed = false;              // the G1 phase is (possibly still) running on the G1 stream
   hipEvent_t sealed_ev = nullptr;   // recorded behind it
   hipStream_t sealed_stream = nullptr;  // where the last seal ran (nullptr: main stream)
+  bool g1_deferred = false;             // sealed, Fr phase submitted, G1 phase waiting in ctx->g1_pending for partners ("g1_batch")
+  uint64_t* pending_out8 = nullptr;     // where that G1 phase leaves the digest lanes
+  std::vector<hipEvent_t> pending_early;  // events behind the openings' scalar preparation (the G1 phase may start behind them)
+  bool pending_early_ok = false;        // this proof's MSM inputs are complete behind the batch's early events (its own or a merged partner's)
+  int submit_g1(uint64_t* out8_d, const std::vector<hipEvent_t>* early, bool early_ok);  // run the G1 phase now or leave it with ctx->g1_pending
   int flush();                      // run pending MSMs on the main stream, canonicalise their outputs
   int seal(uint64_t* out8_d);       // the same plus the digest, on the G1 stream, with no main-stream wait
   int seal_pair(zk_transcript* other, uint64_t* out8_d, uint64_t* other_out8_d);  // two proofs: ONE zipped Fr phase, then each one's G1 phase
-  int g1_phase(uint64_t* out8_d);   // the part of seal() after the Fr phase
+  int g1_phase(uint64_t* out8_d, const std::vector<hipEvent_t>* early = nullptr);   // the part of seal() after the Fr phase
   void unseal();                    // main stream waits for a sealed G1 phase; its scalars are released
 };
 
@@ -101,6 +106,12 @@ int msm_run_derives(zk_ctx* ctx, const std::vector<DeriveJobHost>& derives);
 int msm_flush(zk_ctx* ctx, MsmQueue* queue);
 int msm_run_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs, uint32_t c);
 int g1_canonicalise_dev(zk_ctx* ctx, G1J* pts, uint32_t n);
+struct CanonRanges {  // up to 8 ranges of points put into canonical form by ONE launch
+  G1J* p[8];
+  uint32_t n[8];
+  uint32_t cnt;
+};
+int g1_canonicalise_multi_dev(zk_ctx* ctx, const CanonRanges& r);
 int commit_dev(zk_ctx* ctx, zk_gens* gens, const Fr* t, uint32_t tn, G1J* out);
 // queue == nullptr: run now; otherwise (PIPPENGER back end) the MSMs are deferred to msm_flush(queue)
 int me_open_dev(zk_ctx* ctx, zk_gens* gens, const Fr* t, const Fr* u_d, uint32_t k, G1J* proof_d, Fr* ret_d, MsmQueue* queue, const G1J* com_eval_d = nullptr);

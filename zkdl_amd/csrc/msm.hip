@@ -561,6 +561,28 @@ int g1_canonicalise_dev(zk_ctx* ctx, G1J* pts, uint32_t n) {
   return ZK_OK;
 }
 
+// the same over up to 8 ranges in ONE launch (the G1 phases of several proofs run as one batch: the inversion's latency is paid once)
+__global__ void __launch_bounds__(64) k_g1_canonicalise_multi(CanonRanges r) {
+  __shared__ Fq wtab[16 * 64];
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  G1J* pts = nullptr;
+  for (uint32_t q = 0; q < r.cnt; q++) {
+    if (pts) break;
+    if (i < r.n[q]) pts = r.p[q];
+    else i -= r.n[q];
+  }
+  if (!pts) return;
+  G1J p = pts[i];
+  if (!l_is_zero(p.z) && l_eq(p.z, fp_one())) return;
+  pts[i] = g1q_canonical(g1q_from_jacobian(p), wtab + threadIdx.x, 64);
+}
+int g1_canonicalise_multi_dev(zk_ctx* ctx, const CanonRanges& r) {
+  uint32_t n = 0;
+  for (uint32_t q = 0; q < r.cnt; q++) n += r.n[q];
+  if (n) ZK_LAUNCH(ctx, "g1_canonicalise", 288ull * n, k_g1_canonicalise_multi, dim3((n + 63) / 64), dim3(64), 0, r);
+  return ZK_OK;
+}
+
 uint32_t msm_pick_window(zk_ctx* ctx, uint32_t bits) {
   if (ctx->msm_window) return ctx->msm_window < 2 ? 2 : (ctx->msm_window > 13 ? 13 : ctx->msm_window);
   return bits <= 24 ? 7 : 10;  // short scalars (quantised weights): two 7-bit windows; full width: 26 x 10 bits

@@ -22,11 +22,12 @@ int rec_begin_chain(zk_ctx* ctx, Recorder* r, uint32_t group) {
   return ZK_OK;
 }
 
-void rec_split(zk_ctx* ctx, uint32_t group) {
+void rec_split(zk_ctx* ctx, uint32_t group, bool early) {
   Recorder* r = ctx->rec;
   if (!r) return;
   if (!r->chains.back().ops.empty()) r->chains.emplace_back();
   r->chains.back().group = group;
+  r->chains.back().early = early;
 }
 
 void rec_end_chain(zk_ctx* ctx) { ctx->rec = nullptr; }
@@ -75,11 +76,13 @@ struct Batch {
   size_t table_off;  // job table inside the blob
   uint64_t bytes;
   uint32_t group;
+  bool early = false;      // belongs to the group's early chains
+  bool early_end = false;  // last launch of the group's early chains
 };
 inline bool same_key(const RecOp& a, const RecOp& b) { return a.k && b.k == a.k && b.gy == a.gy && b.shmem == a.shmem; }
 }  // namespace
 
-int rec_execute(zk_ctx* ctx, Recorder* r, bool join) {
+int rec_execute(zk_ctx* ctx, Recorder* r, bool join, std::vector<hipEvent_t>* early_out) {
   if (r->chains.empty()) return ZK_OK;
   Recorder* outer = ctx->rec;
   ctx->rec = nullptr;  // launches below are real
@@ -99,23 +102,32 @@ int rec_execute(zk_ctx* ctx, Recorder* r, bool join) {
   int rc = ZK_OK;
   std::vector<size_t> members;
   for (uint32_t g : groups) {
+    bool early_phase = false;  // the group's early chains are zipped (among themselves) and launched before its other chains
+    for (auto& c : r->chains)
+      if (c.group == g && c.early && !c.ops.empty()) early_phase = true;
     for (;;) {
       size_t best = nc, best_left = 0;
       for (size_t c = 0; c < nc; c++) {
-        if (r->chains[c].group != g) continue;
+        if (r->chains[c].group != g || (early_phase && !r->chains[c].early)) continue;
         size_t left = r->chains[c].ops.size() - head[c];
         if (left > best_left) {
           best = c;
           best_left = left;
         }
       }
-      if (best == nc) break;
+      if (best == nc) {
+        if (!early_phase) break;
+        early_phase = false;
+        if (!batches.empty() && batches.back().group == g) batches.back().early_end = true;
+        continue;
+      }
       const RecOp& a = r->chains[best].ops[head[best]];
       Batch b;
       b.first = &a;
       b.bytes = 0;
       b.table_off = 0;
       b.group = g;
+      b.early = early_phase;
       if (!a.k) {
         b.grid = dim3(1);
         head[best]++;
@@ -125,7 +137,7 @@ int rec_execute(zk_ctx* ctx, Recorder* r, bool join) {
       members.clear();
       uint32_t gx = 0;
       for (size_t d = 0; d < nc; d++) {
-        if (r->chains[d].group != g || head[d] >= r->chains[d].ops.size()) continue;
+        if (r->chains[d].group != g || head[d] >= r->chains[d].ops.size() || (early_phase && !r->chains[d].early)) continue;
         const RecOp& o = r->chains[d].ops[head[d]];
         if (same_key(a, o)) {
           members.push_back(d);
@@ -177,8 +189,16 @@ int rec_execute(zk_ctx* ctx, Recorder* r, bool join) {
   }
   auto stream_of = [&](uint32_t g) -> hipStream_t { return (g == 0 || !fan_out) ? home : ctx->lanes[(g - 1) % ctx->lanes.size()].stream; };
   static const bool skip_fr = experiment_on("ZKDL_EXPERIMENT_SKIP_FR");  // timing experiments only: nothing recorded is launched
-  for (size_t i = 0; i < batches.size() && rc == ZK_OK && !skip_fr; i++) {
-    const Batch& b = batches[i];
+  // early batches of every group are enqueued first (the host needs ~0.5 ms to enqueue a proof's ~90 launches: whoever waits for the
+  // early events should not wait for the host to get through the other groups); per stream the order is unchanged
+  std::vector<size_t> order;
+  order.reserve(batches.size());
+  for (size_t i = 0; i < batches.size(); i++)
+    if (batches[i].early) order.push_back(i);
+  for (size_t i = 0; i < batches.size(); i++)
+    if (!batches[i].early) order.push_back(i);
+  for (size_t oi = 0; oi < order.size() && rc == ZK_OK && !skip_fr; oi++) {
+    const Batch& b = batches[order[oi]];
     ctx->stream = stream_of(b.group);
     int lr;
     {
@@ -186,6 +206,13 @@ int rec_execute(zk_ctx* ctx, Recorder* r, bool join) {
       lr = b.first->k ? b.first->k->launch_many(ctx->stream, b.grid, b.first->shmem, r->blob_dev + b.table_off) : b.first->opaque(ctx->stream);
     }
     if (lr != 0) rc = ctx->fail(ZK_ERR_DEVICE, std::string("launch of ") + b.first->name + " failed: " + hipGetErrorString(hipGetLastError()));
+    if (b.early_end && early_out && rc == ZK_OK) {
+      hipEvent_t e = ctx->get_event();
+      if (e) {
+        (void)hipEventRecord(e, ctx->stream);
+        early_out->push_back(e);
+      }
+    }
   }
   ctx->stream = home;
   for (zk_ctx::Lane* l : used) {
