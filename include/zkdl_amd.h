@@ -299,6 +299,26 @@ int zk_verify_relu(zk_ctx* ctx, uint32_t n, const zk_fr* u_z_h, const zk_fr* v_z
 int zk_fs_derive(const uint8_t* seed32, uint32_t layer, uint32_t kind, uint32_t vec, uint32_t len, zk_fr* out_h);
 int zk_sha256(const void* data, size_t len, uint8_t* out32);
 
+/* ---------------------------------------------------------------- round-by-round Fiat-Shamir ("sound mode")
+ * zk_fc_prove / zk_relu_prove take every challenge as an argument, like the reference's pre-drawn coins (proof.cu:3-11): that is the
+ * reference-parity interface, and with zk_fs_derive a reproducible public-coin schedule -- but a prover who knows round r's challenge
+ * before sending round r's message is not bound by it.  The *_fs entry points derive the challenges themselves:
+ *   evaluation points fixed before a sub-protocol starts (zkFC: u_bs, u_out; zkReLU: u_z, u_r, u_rec, u_hp) = zk_fs_derive(seed32, layer, kind, vec, .)
+ *   with vec = the position in the reference's draw order (zkfc.cu:135-137, zkrelu.cu:85-98);
+ *   every sumcheck ROUND challenge (zkFC: u_in; zkReLU: v_z, v_r, v_hp)  x_r = H(state_r),  state_{r+1} = SHA-256(state_r | c0 | c1 | c2) over the
+ *   round's three coefficients as the transcript holds them (32 bytes each), state_0 = SHA-256("zkdl-amd/fs-rounds/v1" | seed32 | layer | kind |
+ *   which), which = 0 (zkFC inner product), 1 / 2 / 3 (zkReLU magnitude bits, remainder bits, Hadamard); integers as 4 little-endian bytes;
+ *   x_r = the digest read as 8 little-endian uint32 limbs, top limb mod 1944954707 (random_vec's distribution).
+ * The hash runs on the device between a round's message and its fold (no host round trip); the opening's point u_out || u_in exists only after
+ * the sumcheck, so it is proved behind it.  seed32: a digest of the public statement (zkdl_amd/proof.py: statement_digest).  The transcript
+ * has the layout of zk_fc_prove / zk_relu_prove; zk_fs_round_challenges re-derives the round challenges from it (coeffs_h: the k coefficient
+ * triples), after which zk_verify_fc / zk_verify_relu check the proof as before.  Fed the derived challenges, zk_fc_prove / zk_relu_prove
+ * (and the CPU oracle) produce the same transcript bit for bit. */
+int zk_fc_prove_fs(zk_ctx* ctx, zk_fc* fc, const zk_fr* x_d, uint32_t xn, const zk_fr* z_d, uint32_t zn, zk_gens* gens, const uint8_t* seed32, uint32_t layer,
+                   zk_transcript* tr);
+int zk_relu_prove_fs(zk_ctx* ctx, const zk_relu* relu, const zk_fr* x_d, const zk_fr* z_d, uint32_t n, const uint8_t* seed32, uint32_t layer, zk_transcript* tr);
+int zk_fs_round_challenges(const uint8_t* seed32, uint32_t layer, uint32_t kind, uint32_t which, const zk_fr* coeffs_h, uint32_t k, zk_fr* out_h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,7 +34,7 @@ zk_fc_out zk_fc_com_size zk_fc_weights zk_fc_com zk_fc_load_input zk_fc_forward 
 zk_relu_destroy zk_relu_forward zk_relu_sign zk_relu_mag_bin zk_relu_rem_bin zk_relu_prove zk_transcript_create
 zk_transcript_destroy zk_transcript_reset zk_transcript_flush zk_transcript_counts zk_transcript_read zk_transcript_read_affine
 zk_transcript_digest zk_transcript_digest_dev zk_transcript_serialize zk_transcript_seal zk_transcript_seal_pair zk_transcript_stream
-zk_verify_fc zk_verify_relu zk_verify_open zk_fs_derive zk_sha256""".split()
+zk_verify_fc zk_verify_relu zk_verify_open zk_fs_derive zk_sha256 zk_fc_prove_fs zk_relu_prove_fs zk_fs_round_challenges""".split()
 
 
 class ZkError(RuntimeError):
@@ -513,6 +513,24 @@ def fs_derive(seed32, layer, kind, vec, n, lib=None):
     return out[:n]
 
 
+def fs_round_challenges(seed32, layer, kind, which, coeffs, lib=None):
+    """The k round challenges of one sumcheck, re-derived from its coefficient triples (zk_fs_round_challenges; host code)."""
+    lib = lib or load_library()
+    seed32 = bytes(seed32)
+    if len(seed32) != 32:
+        raise ValueError("seed must be 32 bytes")
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.uint32).reshape(-1, 8)
+    if coeffs.shape[0] % 3:
+        raise ValueError("coefficient triples expected")
+    k = coeffs.shape[0] // 3
+    out = np.zeros((max(k, 1), 8), dtype=np.uint32)
+    src = coeffs if k else np.zeros((3, 8), dtype=np.uint32)
+    rc = lib.zk_fs_round_challenges(seed32, _u32(layer), _u32(kind), _u32(which), _hp(src), _u32(k), _hp(out))
+    if rc != ZK_OK:
+        raise ZkError(rc, "zk_fs_round_challenges failed")
+    return out[:k]
+
+
 class Gens:
     """Commitment object (commitment.cuh:8-23): generator tensor + lazily built MSM window tables."""
 
@@ -642,6 +660,11 @@ class FC:
         zk._chk(zk.lib.zk_fc_prove(zk.ctx, self.h, _vp(x.ptr), _u32(x.n), _vp(z.ptr), _u32(z.n), gens.h,
                                    _hp(_fr_host(u_bs)), _hp(_fr_host(u_in)), _hp(_fr_host(u_out)), tr.h))
 
+    def prove_fs(self, x, z, gens, seed32, layer, tr):
+        """zkFC::prove with round-by-round Fiat-Shamir challenges (zk_fc_prove_fs)."""
+        zk = self.zk
+        zk._chk(zk.lib.zk_fc_prove_fs(zk.ctx, self.h, _vp(x.ptr), _u32(x.n), _vp(z.ptr), _u32(z.n), gens.h, bytes(seed32), _u32(layer), tr.h))
+
     def close(self):
         if self.h:
             self.zk.lib.zk_fc_destroy(self.h)
@@ -674,6 +697,11 @@ class ReLU:
         zk = self.zk
         hs = [_hp(_fr_host(c)) for c in ch]
         zk._chk(zk.lib.zk_relu_prove(zk.ctx, self.h, _vp(x.ptr), _vp(z.ptr), _u32(x.n), *hs, tr.h))
+
+    def prove_fs(self, x, z, seed32, layer, tr):
+        """zkReLU::prove with round-by-round Fiat-Shamir challenges (zk_relu_prove_fs)."""
+        zk = self.zk
+        zk._chk(zk.lib.zk_relu_prove_fs(zk.ctx, self.h, _vp(x.ptr), _vp(z.ptr), _u32(x.n), bytes(seed32), _u32(layer), tr.h))
 
     def close(self):
         if self.h:

@@ -11,7 +11,7 @@ import struct
 
 import numpy as np
 
-from .capi import fs_derive, sha256
+from .capi import fs_derive, fs_round_challenges, sha256
 
 KIND_FC, KIND_RELU = 0, 1
 
@@ -65,6 +65,58 @@ def fs_challenges(seed, dims, batch):
             lens = (k + 5, k + 5, k + 4, k + 4, k, k, k)
             out.append(("relu", i, [fs_derive(seed, i, KIND_RELU, v, n) for v, n in enumerate(lens)]))
     return out
+
+
+# ------------------------------------------------------------------ round-by-round Fiat-Shamir ("sound mode": zk_fc_prove_fs / zk_relu_prove_fs)
+def prove_mlp_fs(fcs, relus, gens, X, Z, A, Yhat, seed, tr):
+    """The reference's timed loop (demo.cu:124-138) with every challenge derived by the library: evaluation points from the statement digest
+    `seed`, every sumcheck round challenge from a hash of the rounds before it (csrc/fs_rounds.hip)."""
+    L = len(fcs)
+    tr.reset()
+    fcs[L - 1].prove_fs(A[L - 2] if L > 1 else X, Yhat, gens[L - 1], seed, L - 1, tr)
+    for i in range(L - 2, -1, -1):
+        relus[i].prove_fs(Z[i], A[i], seed, i, tr)
+        fcs[i].prove_fs(A[i - 1] if i > 0 else X, Z[i], gens[i], seed, i, tr)
+
+
+def fs_round_mode_challenges(seed, dims, batch, fr):
+    """Every challenge vector of a proof made by prove_mlp_fs, re-derived from the statement digest and the proof's own Fr values `fr`
+    (the verifier's derivation): the list has fs_challenges()'s shape, so verify_mlp -- and the oracle -- take it as they take any other."""
+    sh = layer_shapes(dims)
+    kb = ceil_log2(1 << ceil_log2(batch))
+    out, off = [], 0
+    for kind, i in call_order(len(sh)):
+        s = sh[i]
+        if kind == "fc":
+            k_in, k_out = ceil_log2(s["in_p"]), ceil_log2(s["out_p"])
+            u_in = fs_round_challenges(seed, i, KIND_FC, 0, fr[off:off + 3 * k_in])
+            out.append(("fc", i, [fs_derive(seed, i, KIND_FC, 0, kb), u_in, fs_derive(seed, i, KIND_FC, 2, k_out)]))
+            off += 3 * k_in + 4
+        else:
+            k = kb + ceil_log2(s["out_p"])
+            o_mag, o_rem = off, off + 3 * (k + 5) + 1 + 32
+            o_hp = o_rem + 3 * (k + 4) + 1 + 16
+            v_z = fs_round_challenges(seed, i, KIND_RELU, 1, fr[o_mag:o_mag + 3 * (k + 5)])
+            v_r = fs_round_challenges(seed, i, KIND_RELU, 2, fr[o_rem:o_rem + 3 * (k + 4)])
+            v_hp = fs_round_challenges(seed, i, KIND_RELU, 3, fr[o_hp:o_hp + 3 * k])
+            out.append(("relu", i, [fs_derive(seed, i, KIND_RELU, 0, k + 5), v_z, fs_derive(seed, i, KIND_RELU, 2, k + 4), v_r,
+                                    fs_derive(seed, i, KIND_RELU, 4, k), fs_derive(seed, i, KIND_RELU, 5, k), v_hp]))
+            off = o_hp + 3 * k + 2
+    if off != fr.shape[0]:
+        raise ValueError("transcript does not have the shape of this model's proof")
+    return out
+
+
+def verify_mlp_fs(zk, dims, batch, gens, coms, x_fr, y_fr, blob):
+    """Verify a proof made by prove_mlp_fs: the challenges are re-derived from the statement AND the proof's round messages, then every
+    check of verify_mlp runs.  A changed round message changes every later challenge of its sumcheck, so the prover cannot have chosen the
+    message knowing them.  Returns (ok, message, open_claims)."""
+    try:
+        fr, _, _ = parse_transcript(blob)
+        chal = fs_round_mode_challenges(statement_digest(zk, dims, batch, gens, coms, x_fr, y_fr), dims, batch, fr)
+    except ValueError as e:
+        return False, str(e), []
+    return verify_mlp(zk, dims, batch, gens, coms, x_fr, y_fr, blob, chal=chal)
 
 
 def parse_transcript(blob):
