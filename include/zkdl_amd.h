@@ -220,6 +220,24 @@ int zk_relu_prove(zk_ctx* ctx, const zk_relu* relu, const zk_fr* x_d, const zk_f
                   const zk_fr* u_z_h, const zk_fr* v_z_h, const zk_fr* u_r_h, const zk_fr* v_r_h, const zk_fr* u_rec_h,
                   const zk_fr* u_hp_h, const zk_fr* v_hp_h, zk_transcript* tr);
 
+/* ---- activation kinds beyond the reference's ReLU (an extension: zkrelu.cu:11-41 is the reference's only activation).
+ * kind 0 = ReLU (default), 1 = LeakyReLU with negative slope 2^-shift (shift 0: identity, i.e. a signed requantisation -- what a Linear layer
+ * followed directly by another Linear layer needs).  Same decomposition as ReLU (sign, the 32 magnitude bits of the rescaled value, 16
+ * remainder bits: zkrelu.cu:11-41).  For a negative input the reference's kernel decomposes x + 2^47, i.e. mag_rescaled = 2^31 + q is the offset
+ * encoding of the requantised value q < 0, and floor(q / 2^shift) = (mag_rescaled >> shift) - 2^(31 - shift): magnitude bits shift..31 minus a
+ * constant, so the bit tensors the prover already has cover it.  Takes effect at the next zk_relu_forward. */
+int zk_relu_set_activation(zk_relu* relu, uint32_t kind, uint32_t shift);
+/* zk_relu_prove's transcript followed by hadamard_product_sumcheck(low, 1 - sign, u_lk, v_lk) (proof.cu:110-150; 3k+2 more Fr values), low =
+ * mont(mag_rescaled >> shift): the negative branch's magnitude (low o (1 - sign))~(u_lk), in the style of the reference's (Z o sign)~(u_hp).
+ * A = mont(mag_rescaled) o sign + (low - 2^(31 - shift)) o (1 - sign). */
+int zk_leaky_prove(zk_ctx* ctx, const zk_relu* relu, const zk_fr* x_d, const zk_fr* z_d, uint32_t n,
+                   const zk_fr* u_z_h, const zk_fr* v_z_h, const zk_fr* u_r_h, const zk_fr* v_r_h, const zk_fr* u_rec_h,
+                   const zk_fr* u_hp_h, const zk_fr* v_hp_h, const zk_fr* u_lk_h, const zk_fr* v_lk_h, zk_transcript* tr);
+/* zk_verify_relu's checks plus the extra Hadamard sumcheck; claims_h[0..5) as zk_verify_relu, claims_h[5..8) = (low o nsign)~(u_lk), low~(v_lk),
+ * nsign~(v_lk) */
+int zk_verify_leaky(zk_ctx* ctx, uint32_t n, const zk_fr* u_z_h, const zk_fr* v_z_h, const zk_fr* u_r_h, const zk_fr* v_r_h, const zk_fr* u_hp_h,
+                    const zk_fr* v_hp_h, const zk_fr* u_lk_h, const zk_fr* v_lk_h, const zk_fr* fr_h, size_t n_fr, zk_fr* claims_h, int* ok);
+
 /* ---------------------------------------------------------------- transcript */
 int zk_transcript_create(zk_ctx* ctx, zk_transcript** out);
 int zk_transcript_destroy(zk_transcript* tr);

@@ -340,6 +340,26 @@ class Oracle:
             raise ValueError("Incompatible dimensions")
         return fr_out[:nf.value]
 
+    def leaky_forward(self, X, shift):
+        """LeakyReLU with negative slope 2^-shift (extension; shift 0 = identity): (A, sign, mag_bin, rem_bin, low, nsign)."""
+        X = _c(X, 8)
+        n = X.shape[0]
+        Z, sign, mag, rem, low, nsign = fr(n), fr(n), fr(32 * n), fr(16 * n), fr(n), fr(n)
+        self.lib.zo_leaky_forward(_p(X), _sz(n), _u32(shift), _p(Z), _p(sign), _p(mag), _p(rem), _p(low), _p(nsign))
+        return Z, sign, mag, rem, low, nsign
+
+    def leaky_prove(self, X, Z, sign, mag, rem, low, nsign, u_z, v_z, u_r, v_r, u_rec, u_hp, v_hp, u_lk, v_lk):
+        X, Z, sign, mag, rem, low, nsign = [_c(t, 8) for t in (X, Z, sign, mag, rem, low, nsign)]
+        ch = [_c(x, 8) for x in (u_z, v_z, u_r, v_r, u_rec, u_hp, v_hp, u_lk, v_lk)]
+        n = X.shape[0]
+        k = self.ceil_log2(n)
+        fr_out = fr(3 * (k + 5) + 1 + 32 + 3 * (k + 4) + 1 + 16 + 2 * (3 * k + 2) + 8)
+        nf = _sz(0)
+        rc = self.lib.zo_leaky_prove(_p(X), _p(Z), _sz(n), _p(sign), _p(mag), _p(rem), _p(low), _p(nsign), *[_p(c) for c in ch], _p(fr_out), ctypes.byref(nf))
+        if rc:
+            raise ValueError("Incompatible dimensions")
+        return fr_out[:nf.value]
+
     def num_threads(self):
         return int(self.lib.zo_num_threads())
 

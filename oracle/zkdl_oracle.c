@@ -750,6 +750,44 @@ int zo_relu_prove(const zo_fr* X, const zo_fr* Z, size_t n, const zo_fr* sign, c
   return rc;
 }
 
+/* ---- LeakyReLU with negative slope 2^-shift (shift 0: identity, i.e. signed requantisation) -- an EXTENSION: the reference's only
+ * activation is zkReLU (zkrelu.cu:11-41).  Same decomposition as zo_relu_forward (sign, 32 magnitude bits of the rescaled value,
+ * 16 remainder bits).  For a negative input the reference's kernel decomposes x + 2^47 (zkrelu.cu:19-22), so the "magnitude" it
+ * stores is the OFFSET encoding mag_rescaled = 2^31 + q of the requantised value q = round(x / 2^16) < 0, and
+ *     floor(q / 2^shift) = (mag_rescaled >> shift) - 2^(31 - shift)
+ * exactly (arithmetic shift, rounding toward -infinity): the magnitude bits shift .. 31 minus a constant, so no further bit tensor
+ * is needed.  low[g] = mont(mag_rescaled >> shift), nsign[g] = 1 - sign[g], and the negative branch outputs low - 2^(31 - shift). */
+void zo_leaky_forward(const zo_fr* X, size_t n, uint32_t shift, zo_fr* Z, zo_fr* sign, zo_fr* mag_bin, zo_fr* rem_bin, zo_fr* low, zo_fr* nsign) {
+  zo_relu_forward(X, n, Z, sign, mag_bin, rem_bin);
+#pragma omp parallel for if (n > 1024)
+  for (size_t g = 0; g < n; g++) {
+    uint32_t m = 0;
+    for (unsigned i = 0; i < 32; i++)
+      if (mag_bin[g * 32 + i].v[0] | mag_bin[g * 32 + i].v[7]) m |= 1u << i;   /* FR_ONE is non-zero in limbs 0 and 7 */
+    zo_fr lo = FR_0; lo.v[0] = shift < 32 ? (m >> shift) : 0u;
+    low[g] = fr_mont(lo);
+    int positive = (sign[g].v[0] | sign[g].v[7]) != 0;
+    nsign[g] = positive ? FR_0 : FR_ONE;
+    if (!positive) {
+      zo_fr c = FR_0; c.v[0] = shift < 32 ? (1u << (31 - shift)) : 0u;
+      Z[g] = fr_sub(low[g], fr_mont(c));
+    }
+  }
+}
+/* zkReLU::prove's transcript (zkrelu.cu:74-100) followed by hadamard_product_sumcheck(low, nsign, u_lk, v_lk) (proof.cu:110-150):
+ * the negative branch's magnitude (low o nsign)~(u_lk), in the style of the reference's (Z o sign) sumcheck */
+int zo_leaky_prove(const zo_fr* X, const zo_fr* Z, size_t n, const zo_fr* sign, const zo_fr* mag_bin, const zo_fr* rem_bin, const zo_fr* low, const zo_fr* nsign,
+                   const zo_fr* u_z, const zo_fr* v_z, const zo_fr* u_r, const zo_fr* v_r, const zo_fr* u_rec,
+                   const zo_fr* u_hp, const zo_fr* v_hp, const zo_fr* u_lk, const zo_fr* v_lk, zo_fr* fr_out, size_t* n_fr) {
+  size_t p = 0;
+  int rc = zo_relu_prove(X, Z, n, sign, mag_bin, rem_bin, u_z, v_z, u_r, v_r, u_rec, u_hp, v_hp, fr_out, &p);
+  if (rc) return rc;
+  size_t k = zo_ceil_log2((uint32_t)n);
+  rc = zo_hadamard_product_sumcheck(low, nsign, n, u_lk, v_lk, k, fr_out + p); p += 3 * k + 2;
+  *n_fr = p;
+  return rc;
+}
+
 int zo_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -121,6 +121,11 @@ int zo_fc_prove(const zo_fr* X, size_t xn, const zo_fr* Z, size_t zn, const zo_f
 int zo_relu_prove(const zo_fr* X, const zo_fr* Z, size_t n, const zo_fr* sign, const zo_fr* mag_bin, const zo_fr* rem_bin,
                   const zo_fr* u_z, const zo_fr* v_z, const zo_fr* u_r, const zo_fr* v_r, const zo_fr* u_rec,
                   const zo_fr* u_hp, const zo_fr* v_hp, zo_fr* fr_out, size_t* n_fr);
+/* extension (no reference counterpart): LeakyReLU with slope 2^-shift on the negative branch; see zkdl_oracle.c */
+void zo_leaky_forward(const zo_fr* X, size_t n, uint32_t shift, zo_fr* Z, zo_fr* sign, zo_fr* mag_bin, zo_fr* rem_bin, zo_fr* low, zo_fr* nsign);
+int zo_leaky_prove(const zo_fr* X, const zo_fr* Z, size_t n, const zo_fr* sign, const zo_fr* mag_bin, const zo_fr* rem_bin, const zo_fr* low, const zo_fr* nsign,
+                   const zo_fr* u_z, const zo_fr* v_z, const zo_fr* u_r, const zo_fr* v_r, const zo_fr* u_rec,
+                   const zo_fr* u_hp, const zo_fr* v_hp, const zo_fr* u_lk, const zo_fr* v_lk, zo_fr* fr_out, size_t* n_fr);
 
 int zo_num_threads(void);
 

@@ -196,3 +196,38 @@ def test_demo_driver_at_the_headline_configuration(tmp_path):
         with open(os.path.join(keep, "demo_headline.txt"), "w") as f:
             f.write("$ python -m zkdl_amd.model && ./demo traced_model.pt sample_input.pt --seed 5 --repeat 3\n" + run.stdout)
             f.write("\n$ ./demo traced_model.pt sample_input.pt --fs --verify --repeat 1\n" + run2.stdout)
+
+
+def test_demo_loads_leaky_identity_and_bare_linear_stacks(tmp_path):
+    """SURVEY 8f-3, non-ReLU activations through the reference's driver surface: nn.LeakyReLU(2^-3), nn.Identity and two Linear layers with
+    nothing between them.  demo.out de-quantises to the float model; the proof (one more Hadamard sumcheck per non-ReLU activation)
+    verifies with hash-derived challenges; a slope that is not a power of two is refused."""
+    exe = os.path.join(HOST, "demo")
+    if not os.path.exists(exe):
+        pytest.skip("zkdl_amd/host/demo not built (needs LibTorch)")
+    import torch
+    import bigint_model as bm
+    d = str(tmp_path)
+    subprocess.run([sys.executable, "-m", "zkdl_amd.model", "--dims", "12,20,9,11,7", "--batch", "5", "--seed", "4", "--act", "leaky:3,identity,none", "--out-dir", d],
+                   check=True, cwd=ROOT)
+    run = subprocess.run([exe, os.path.join(d, "traced_model.pt"), os.path.join(d, "sample_input.pt"), "--fs", "--verify"], capture_output=True, text=True, cwd=d, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "Verification: OK" in run.stdout
+    vals = [int(x, 16) for x in open(os.path.join(d, "demo.out")).read().strip().strip("[]").split("\n")]
+    assert len(vals) == 8 * 8
+    m = torch.jit.load(os.path.join(d, "traced_model.pt"))
+    x = list(torch.jit.load(os.path.join(d, "sample_input.pt")).parameters())[0].detach()
+    with torch.no_grad():
+        want = m(x).double().numpy()
+    got = np.array([(v - bm.R_MOD if v > bm.R_MOD // 2 else v) / 2.0 ** 32 for v in vals]).reshape(8, 8)
+    assert np.abs(got[:5, :7] - want).max() < 2e-3
+    # the transcript is longer than the all-ReLU one by 3 x (3k + 2) values: B_p = 8, out_p = 32, 16, 16 -> k = 8, 7, 7
+    n_fr = int(run.stdout.split("Transcript: ")[1].split(" Fr")[0])
+    subprocess.run([sys.executable, "-m", "zkdl_amd.model", "--dims", "12,20,9,11,7", "--batch", "5", "--seed", "4", "--out-dir", d], check=True, cwd=ROOT)
+    run_relu = subprocess.run([exe, os.path.join(d, "traced_model.pt"), os.path.join(d, "sample_input.pt"), "--fs", "--verify"], capture_output=True, text=True, cwd=d, timeout=600)
+    assert run_relu.returncode == 0 and "Verification: OK" in run_relu.stdout
+    assert n_fr - int(run_relu.stdout.split("Transcript: ")[1].split(" Fr")[0]) == (3 * 8 + 2) + 2 * (3 * 7 + 2)
+    subprocess.run([sys.executable, "-c", "import torch, torch.nn as nn, zkdl_amd.model as M; m = nn.Sequential(nn.Linear(6, 5, bias=False), nn.LeakyReLU(0.01), "
+                    "nn.Linear(5, 4, bias=False)).eval(); x = torch.randn(3, 6); M.save_tensor(x, '%s/x.pt'); torch.jit.trace(m, x[:1]).save('%s/m.pt')" % (d, d)], check=True, cwd=ROOT)
+    bad = subprocess.run([exe, os.path.join(d, "m.pt"), os.path.join(d, "x.pt")], capture_output=True, text=True, cwd=d, timeout=600)
+    assert bad.returncode != 0 and "not a power of two" in (bad.stdout + bad.stderr)

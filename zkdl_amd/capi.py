@@ -34,7 +34,7 @@ zk_fc_out zk_fc_com_size zk_fc_weights zk_fc_com zk_fc_load_input zk_fc_forward 
 zk_relu_destroy zk_relu_forward zk_relu_sign zk_relu_mag_bin zk_relu_rem_bin zk_relu_prove zk_transcript_create
 zk_transcript_destroy zk_transcript_reset zk_transcript_flush zk_transcript_counts zk_transcript_read zk_transcript_read_affine
 zk_transcript_digest zk_transcript_digest_dev zk_transcript_serialize zk_transcript_seal zk_transcript_seal_pair zk_transcript_stream
-zk_verify_fc zk_verify_relu zk_verify_open zk_fs_derive zk_sha256 zk_fc_prove_fs zk_relu_prove_fs zk_fs_round_challenges""".split()
+zk_verify_fc zk_verify_relu zk_verify_open zk_fs_derive zk_sha256 zk_fc_prove_fs zk_relu_prove_fs zk_fs_round_challenges zk_relu_set_activation zk_leaky_prove zk_verify_leaky""".split()
 
 
 class ZkError(RuntimeError):
@@ -472,6 +472,15 @@ class Zk:
                                           _hp(_fr_host(ch[6])), _hp(fr), _sz(fr.shape[0]), _hp(claims), ctypes.byref(ok)))
         return bool(ok.value), ("" if ok.value else self.lib.zk_last_error(self.ctx).decode()), claims
 
+    def verify_leaky(self, n, ch, fr):
+        """zk_verify_leaky: ch = zk_leaky_prove's nine vectors.  Returns (ok, message, claims[8])."""
+        fr = np.ascontiguousarray(fr, dtype=np.uint32).reshape(-1, 8)
+        ok = ctypes.c_int(0)
+        claims = np.zeros((8, 8), np.uint32)
+        self._chk(self.lib.zk_verify_leaky(self.ctx, _u32(n), *[_hp(_fr_host(ch[i])) for i in (0, 1, 2, 3, 5, 6, 7, 8)], _hp(fr), _sz(fr.shape[0]), _hp(claims),
+                                           ctypes.byref(ok)))
+        return bool(ok.value), ("" if ok.value else self.lib.zk_last_error(self.ctx).decode()), claims
+
     # ---- layers
     def float_to_fr(self, fs_d, rows, rows_p, cols, cols_p):
         out = self.empty(rows_p * cols_p, 8)
@@ -697,6 +706,16 @@ class ReLU:
         zk = self.zk
         hs = [_hp(_fr_host(c)) for c in ch]
         zk._chk(zk.lib.zk_relu_prove(zk.ctx, self.h, _vp(x.ptr), _vp(z.ptr), _u32(x.n), *hs, tr.h))
+
+    def set_activation(self, kind, shift=0):
+        """0 = ReLU (default); 1 = LeakyReLU with negative slope 2^-shift (shift 0: identity).  Takes effect at the next forward()."""
+        self.zk._chk(self.zk.lib.zk_relu_set_activation(self.h, _u32(kind), _u32(shift)))
+
+    def prove_leaky(self, x, z, ch, tr):
+        """ch: the reference's seven vectors followed by u_lk, v_lk (zk_leaky_prove)."""
+        zk = self.zk
+        hs = [_hp(_fr_host(c)) for c in ch]
+        zk._chk(zk.lib.zk_leaky_prove(zk.ctx, self.h, _vp(x.ptr), _vp(z.ptr), _u32(x.n), *hs, tr.h))
 
     def prove_fs(self, x, z, seed32, layer, tr):
         """zkReLU::prove with round-by-round Fiat-Shamir challenges (zk_relu_prove_fs)."""

@@ -787,6 +787,22 @@ int zk_relu_prove(zk_ctx* ctx, const zk_relu* relu, const zk_fr* x, const zk_fr*
   return relu_prove(ctx, relu, F(x), F(z), n, u_z, v_z, u_r, v_r, u_rec, u_hp, v_hp, tr);
 }
 
+int zk_relu_set_activation(zk_relu* relu, uint32_t kind, uint32_t shift) {
+  if (!relu || !relu->ctx) return ZK_ERR_ARG;
+  if (kind > 1 || shift > 31) return relu->ctx->fail(ZK_ERR_ARG, "zk_relu_set_activation: kind 0 (ReLU) or 1 (LeakyReLU, negative slope 2^-shift, shift <= 31)");
+  relu->act_kind = kind;
+  relu->act_shift = kind ? shift : 0;
+  return ZK_OK;
+}
+int zk_leaky_prove(zk_ctx* ctx, const zk_relu* relu, const zk_fr* x, const zk_fr* z, uint32_t n, const zk_fr* u_z, const zk_fr* v_z, const zk_fr* u_r, const zk_fr* v_r,
+                   const zk_fr* u_rec, const zk_fr* u_hp, const zk_fr* v_hp, const zk_fr* u_lk, const zk_fr* v_lk, zk_transcript* tr) {
+  CHECK_CTX_NOJOIN(ctx);
+  if (!relu || !tr) return ctx->fail(ZK_ERR_ARG, "null zk_relu / zk_transcript");
+  CHECK_PTR(ctx, x); CHECK_PTR(ctx, z);
+  const zk_fr* ch[9] = {u_z, v_z, u_r, v_r, u_rec, u_hp, v_hp, u_lk, v_lk};
+  return leaky_prove(ctx, relu, F(x), F(z), n, ch, tr);
+}
+
 // ---------------------------------------------------------------- transcript
 int zk_transcript_create(zk_ctx* ctx, zk_transcript** out) {
   CHECK_CTX(ctx);

@@ -135,7 +135,8 @@ __global__ void __launch_bounds__(256) k_gemm_i64_i16(const int64_t* __restrict_
 // Writes the reference's aux tensors (one Fr per bit) AND the same bits packed (32 magnitude bits
 // per element in mag_packed, 16 remainder bits in rem_packed) for the bit-packed prover path.
 __global__ void __launch_bounds__(256) k_relu(const Fr* __restrict__ X, Fr* __restrict__ Z, Fr* __restrict__ sign, uint32_t* __restrict__ mag_packed,
-                                               uint16_t* __restrict__ rem_packed, uint8_t* __restrict__ sign_packed, uint32_t n, uint32_t* __restrict__ out_of_range) {
+                                               uint16_t* __restrict__ rem_packed, uint8_t* __restrict__ sign_packed, uint32_t n, uint32_t* __restrict__ out_of_range,
+                                               uint32_t leaky, uint32_t shift, Fr* __restrict__ low, Fr* __restrict__ nsign) {
   const Fr one = fr_one(), zero = fr_zero();
   for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
     Fr x = fr_unmont(X[g]);
@@ -170,6 +171,19 @@ __global__ void __launch_bounds__(256) k_relu(const Fr* __restrict__ X, Fr* __re
     Fr mr = fr_zero();
     mr.v[0] = mag_rescaled;
     Z[g] = positive ? fr_mont(mr) : zero;  // mont(mag_rescaled) * sign with sign in {ONE, 0}
+    if (leaky) {  // extension: for a negative input mag_rescaled = 2^31 + q (offset encoding of q = round(x / 2^16) < 0, zkrelu.cu:19-22), so
+                  // floor(q / 2^shift) = (mag_rescaled >> shift) - 2^(31 - shift): magnitude bits shift .. 31 minus a constant
+      Fr lo = fr_zero();
+      lo.v[0] = shift < 32u ? (mag_rescaled >> shift) : 0u;
+      lo = fr_mont(lo);
+      low[g] = lo;
+      nsign[g] = positive ? zero : one;
+      if (!positive) {
+        Fr cst = fr_zero();
+        cst.v[0] = shift < 32u ? (1u << (31u - shift)) : 0u;
+        Z[g] = fr_sub(lo, fr_mont(cst));
+      }
+    }
   }
 }
 
@@ -654,10 +668,15 @@ int relu_forward(zk_ctx* ctx, zk_relu* relu, const Fr* x, uint32_t n, Fr* z) {
     }
     relu->cap = n;
   }
+  if (relu->act_kind == 1 && !relu->low) {
+    if (dev_alloc(ctx, (void**)&relu->low, (size_t)relu->cap * sizeof(Fr)) != hipSuccess || dev_alloc(ctx, (void**)&relu->nsign, (size_t)relu->cap * sizeof(Fr)) != hipSuccess)
+      return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: leaky aux tensors");
+  }
   relu->n = n;
   relu->bins_valid = false;  // mag_bin / rem_bin (48 field elements per input) are materialised on demand
   ZK_TRY(dev_zero(ctx, relu->oor, 4));
-  ZK_LAUNCH(ctx, "relu_forward", 32ull * 3 * n, k_relu, dim3(stream_grid(n)), dim3(256), 0, x, z, relu->sign, relu->mag_packed, relu->rem_packed, relu->sign_packed, n, relu->oor);
+  ZK_LAUNCH(ctx, "relu_forward", 32ull * 3 * n, k_relu, dim3(stream_grid(n)), dim3(256), 0, x, z, relu->sign, relu->mag_packed, relu->rem_packed, relu->sign_packed, n, relu->oor,
+            relu->act_kind == 1 ? 1u : 0u, relu->act_shift, relu->low, relu->nsign);
   uint32_t oor = 0;
   ZK_TRY(dev_to_host(ctx, &oor, relu->oor, 4));
   if (oor) return ctx->fail(ZK_ERR_RANGE, "zkReLU: " + std::to_string(oor) + " input(s) outside the +-2^47 window (undefined in the reference)");
@@ -755,6 +774,36 @@ static int relu_prove_body(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const 
   }
   ZK_TRY(sumcheck_hp_dev(ctx, x, relu->sign, n, c + offs[5], c + offs[6], k, out, ctx->relu_packed ? relu->sign_packed : nullptr));
   return ZK_OK;
+}
+
+// LeakyReLU (extension): zkReLU::prove's transcript, then hadamard_product_sumcheck(low, nsign, u_lk, v_lk) -- the negative branch's
+// magnitude (low o nsign)~(u_lk), proved the way the reference proves (Z o sign)~(u_hp) (proof.cu:110-150).  ch_h: the reference's
+// seven vectors followed by u_lk, v_lk (k each).
+int leaky_prove(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const Fr* z, uint32_t n, const zk_fr* const ch_h[9], zk_transcript* tr) {
+  if (relu->act_kind != 1 || !relu->low) return ctx->fail(ZK_ERR_ARG, "zk_leaky_prove: the layer's last forward pass was not a LeakyReLU one");
+  ProveGuard guard(ctx, tr);
+  int rc = relu_prove_body(ctx, relu, x, z, n, ch_h[0], ch_h[1], ch_h[2], ch_h[3], ch_h[4], ch_h[5], ch_h[6], tr);
+  if (rc != ZK_OK) return guard.finish(rc);
+  const uint32_t k = ceil_log2(n);
+  const size_t add_fr = 3 * k + 2;
+  rc = tr->ensure(add_fr, 0);
+  if (rc != ZK_OK) return guard.finish(rc);
+  Fr* out = tr->fr_d + tr->n_fr;
+  tr->n_fr += add_fr;
+  auto body = [&]() -> int {
+    RecScope recording(ctx, &tr->rec, REC_GROUP_FC_A);
+    if (recording.rc != ZK_OK) return recording.rc;
+    LaneScope lane(ctx, recording.on ? ~0u : relu->serial);
+    std::vector<zk_fr> ch(2 * k + 1);
+    for (uint32_t j = 0; j < k; j++) {
+      ch[j] = ch_h[7][j];
+      ch[k + j] = ch_h[8][j];
+    }
+    DBuf<Fr> chd;
+    ZK_TRY(upload_fr(ctx, chd, ch.data(), 2 * k));
+    return sumcheck_hp_dev(ctx, relu->low, relu->nsign, n, chd.get(), chd.get() + k, k, out);
+  };
+  return guard.finish(body());
 }
 
 }  // namespace zk

@@ -56,9 +56,16 @@ struct zk_relu {  // zkReLU, zkrelu.cuh:10-20: aux tensors of the last forward p
   uint16_t* rem_packed = nullptr;  // 15 remainder bits + sign bit
   uint8_t* sign_packed = nullptr;
   uint32_t* oor = nullptr;
+  // activation kind (extension; the reference's only activation is ReLU): 0 = ReLU, 1 = LeakyReLU with negative slope 2^-act_shift
+  // (act_shift 0: identity, a signed requantisation).  low = mont(mag_rescaled >> act_shift), nsign = 1 - sign: written by the forward
+  // pass of a leaky layer, consumed by its extra Hadamard sumcheck
+  uint32_t act_kind = 0, act_shift = 0;
+  zk::Fr *low = nullptr, *nsign = nullptr;
   void free_all() {
     zk::dev_free(ctx, sign); zk::dev_free(ctx, mag_bin); zk::dev_free(ctx, rem_bin);
     zk::dev_free(ctx, mag_packed); zk::dev_free(ctx, rem_packed); zk::dev_free(ctx, sign_packed); zk::dev_free(ctx, oor);
+    zk::dev_free(ctx, low); zk::dev_free(ctx, nsign);
+    low = nsign = nullptr;
     sign = mag_bin = rem_bin = nullptr;
     mag_packed = nullptr; rem_packed = nullptr; sign_packed = nullptr; oor = nullptr;
     cap = n = bins_cap = 0;
@@ -123,6 +130,7 @@ int fc_prove(zk_ctx* ctx, zk_fc* fc, const Fr* x, uint32_t xn, const Fr* z, uint
              const zk_fr* u_bs_h, const zk_fr* u_in_h, const zk_fr* u_out_h, zk_transcript* tr);
 int relu_forward(zk_ctx* ctx, zk_relu* relu, const Fr* x, uint32_t n, Fr* z);
 int relu_materialise_bins(zk_ctx* ctx, zk_relu* relu);
+int leaky_prove(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const Fr* z, uint32_t n, const zk_fr* const ch_h[9], zk_transcript* tr);
 int relu_prove(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const Fr* z, uint32_t n, const zk_fr* u_z_h, const zk_fr* v_z_h, const zk_fr* u_r_h,
                const zk_fr* v_r_h, const zk_fr* u_rec_h, const zk_fr* u_hp_h, const zk_fr* v_hp_h, zk_transcript* tr);
 // g1_kernels.hip

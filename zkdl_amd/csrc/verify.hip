@@ -387,4 +387,41 @@ int zk_verify_relu(zk_ctx* ctx, uint32_t n, const zk_fr* u_z_h, const zk_fr* v_z
   return ZK_OK;
 }
 
+// LeakyReLU (extension): the ReLU checks on the first part of the slice, then the extra Hadamard sumcheck (low o nsign)~(u_lk).
+// claims_h[0..5) as zk_verify_relu; claims_h[5..8) = (low o nsign)~(u_lk), low~(v_lk), nsign~(v_lk) -- open, like the ReLU's.
+int zk_verify_leaky(zk_ctx* ctx, uint32_t n, const zk_fr* u_z_h, const zk_fr* v_z_h, const zk_fr* u_r_h, const zk_fr* v_r_h, const zk_fr* u_hp_h, const zk_fr* v_hp_h,
+                    const zk_fr* u_lk_h, const zk_fr* v_lk_h, const zk_fr* fr_h, size_t n_fr, zk_fr* claims_h, int* ok) {
+  if (!ctx) return ZK_ERR_ARG;
+  if (!fr_h || !ok || n == 0) return ctx->fail(ZK_ERR_ARG, "zk_verify_leaky: null argument");
+  *ok = 0;
+  const uint32_t k = ceil_log2(n);
+  const size_t relu_len = 3 * (size_t)(k + 5) + 1 + 32 + 3 * (size_t)(k + 4) + 1 + 16 + 3 * (size_t)k + 2;
+  if (n_fr != relu_len + 3 * (size_t)k + 2) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
+  if (k && (!u_lk_h || !v_lk_h)) return ctx->fail(ZK_ERR_ARG, "zk_verify_leaky: null challenge vector");
+  int ok1 = 0;
+  ZK_TRY(zk_verify_relu(ctx, n, u_z_h, v_z_h, u_r_h, v_r_h, u_hp_h, v_hp_h, fr_h, relu_len, claims_h, &ok1));
+  if (!ok1) return ZK_OK;
+  Fail fail{ctx, ok};
+  const Fr one = fr_one();
+  const size_t off = relu_len;
+  Fr claim = fr_zero(), claim0 = fr_zero();
+  for (uint32_t r = 0; r < k; r++) {
+    const Fr c0 = ld(fr_h + off + 3 * r), c1 = ld(fr_h + off + 3 * r + 1), c2 = ld(fr_h + off + 3 * r + 2);
+    const Fr ur = ld(u_lk_h + r), p1 = fr_add(c0, fr_add(c1, c2));
+    const Fr lhs = fr_add(fr_mul(fr_sub(one, ur), c0), fr_mul(ur, p1));
+    if (r == 0) claim0 = lhs;
+    else if (!feq(lhs, claim)) return fail("negative-branch Hadamard sumcheck, round " + std::to_string(r) + ": (1 - u) p(0) + u p(1) != claim");
+    claim = poly2(c0, c1, c2, ld(v_lk_h + r));
+  }
+  const Fr ha = ld(fr_h + off + 3 * k), hb = ld(fr_h + off + 3 * k + 1);
+  if (k == 0) claim0 = claim = fr_mul(ha, hb);
+  if (!feq(fr_mul(ha, hb), claim)) return fail("negative-branch Hadamard sumcheck: low~ * nsign~ != final claim");
+  if (claims_h) {
+    const Fr outv[3] = {claim0, ha, hb};
+    memcpy(claims_h + 5, outv, sizeof outv);
+  }
+  *ok = 1;
+  return ZK_OK;
+}
+
 }  // extern "C"

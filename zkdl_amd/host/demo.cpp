@@ -16,6 +16,7 @@
 #include <torch/torch.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <fstream>
 #include <iterator>
@@ -63,7 +64,38 @@ torch::Tensor load_tensor(const string& path) {   // demo.cu:40-46
 // "ones" feature (1.0, i.e. 2^16 after quantisation), every weight matrix one extra input row holding the bias and -- except the
 // last -- one extra output column [0 .. 0 1]^T that passes the ones feature on (Z = 2^32 there, which the ReLU rescales back to
 // 2^16).  The augmented bias-free network computes exactly the biased one, inside the power-of-two padding wherever in + 1 <= in_p.
-vector<zkFC> load_model(const string& model_path, vector<unique_ptr<Commitment>>& generators, bool& has_bias) {
+// The activation between two Linear layers (loader generalisation): nn.ReLU (the reference's only one, demo.cu:61-72 skips
+// it by name), nn.LeakyReLU whose negative slope is a power of two 2^-s, nn.Identity, or nothing at all (= identity: the layers still
+// need the requantisation).  {kind, shift} as zk_relu_set_activation takes them.
+struct Act {
+  uint kind = 0, shift = 0;
+};
+static Act activation_of(const torch::jit::script::Module& child) {
+  const string type = child.type()->name() ? child.type()->name()->qualifiedName() : string();
+  Act a;
+  if (type.find("LeakyReLU") != string::npos) {
+    double slope = 0.01;   // nn.LeakyReLU's default
+    for (const auto* node : child.get_method("forward").graph()->nodes())
+      if (string(node->kind().toQualString()) == "aten::leaky_relu") {
+        auto v = torch::jit::toIValue(node->input(1));
+        if (v && v->isDouble()) slope = v->toDouble();
+        else if (v && v->isInt()) slope = (double)v->toInt();
+      }
+    uint s = 0;
+    while (s < 32 && std::ldexp(1.0, -(int)s) != slope) s++;
+    if (s >= 32) throw std::runtime_error("LeakyReLU: negative slope " + to_string(slope) + " is not a power of two 2^-s, s <= 31");
+    a.kind = 1;
+    a.shift = s;
+  } else if (type.find("Identity") != string::npos) {
+    a.kind = 1;
+    a.shift = 0;
+  } else if (type.find("ReLU") == string::npos) {
+    throw std::runtime_error("unsupported activation module: " + type);
+  }
+  return a;
+}
+
+vector<zkFC> load_model(const string& model_path, vector<unique_ptr<Commitment>>& generators, bool& has_bias, vector<Act>& acts) {
   vector<zkFC> fcs;
   torch::jit::script::Module m;
   try {
@@ -77,7 +109,16 @@ vector<zkFC> load_model(const string& model_path, vector<unique_ptr<Commitment>>
   for (int i = 0;; ++i) {
     if (!m.hasattr(to_string(i))) break;
     auto child = m.attr(to_string(i)).toModule();
-    if (!child.hasattr("weight")) continue;
+    if (!child.hasattr("weight")) {   // an activation: belongs behind the Linear layer before it
+      if (!Ws.empty() && acts.size() + 1 == Ws.size()) acts.push_back(activation_of(child));
+      else throw std::runtime_error("Incompatible number of layers");
+      continue;
+    }
+    if (acts.size() + 1 == Ws.size()) {   // two Linear layers in a row: identity (requantisation only)
+      Act a;
+      a.kind = 1;
+      acts.push_back(a);
+    }
     Ws.push_back(child.attr("weight").toTensor().t().to(torch::kCPU).to(torch::kFloat32).contiguous());   // [in, out]
     torch::Tensor b;
     if (child.hasattr("bias") && child.attr("bias").isTensor()) {
@@ -129,8 +170,14 @@ int main(int argc, char* argv[]) {
   zkdl::challenge_log() = &challenges;
   vector<unique_ptr<Commitment>> generators;
   bool has_bias = false;
-  vector<zkFC> fcs = load_model(argv[1], generators, has_bias);
+  vector<Act> acts;
+  vector<zkFC> fcs = load_model(argv[1], generators, has_bias, acts);
   vector<zkReLU> relus(fcs.size() - 1);
+  if (acts.size() + 1 < fcs.size() || acts.size() > fcs.size()) throw std::runtime_error("Incompatible number of layers");
+  for (size_t i = 0; i + 1 < fcs.size(); i++) {
+    // (with folded biases the constant "ones" feature is positive, so it passes every one of these activations unchanged)
+    if (acts[i].kind) relus[i].set_activation(acts[i].kind, acts[i].shift);
+  }
   vector<FrTensor> Z_vec, A_vec;
   Z_vec.reserve(fcs.size());
   A_vec.reserve(fcs.size());
@@ -251,8 +298,16 @@ int main(int argc, char* argv[]) {
       const uint n = B_p * fcs[i].outputSize, k = ceilLog2(n);
       vector<vector<Fr_t>> ch;
       for (uint l : {k + 5, k + 5, k + 4, k + 4, k, k, k}) ch.push_back(take(l));
-      const size_t nf = 3 * (k + 5) + 1 + 32 + 3 * (k + 4) + 1 + 16 + 3 * k + 2;
-      string msg = zkReLU::verify(n, ch, fr.data() + of, nf);
+      size_t nf = 3 * (k + 5) + 1 + 32 + 3 * (k + 4) + 1 + 16 + 3 * k + 2;
+      string msg;
+      if (relus[i].leaky()) {
+        ch.push_back(take(k));
+        ch.push_back(take(k));
+        nf += 3 * k + 2;
+        msg = zkReLU::verify_leaky(n, ch, fr.data() + of, nf);
+      } else {
+        msg = zkReLU::verify(n, ch, fr.data() + of, nf);
+      }
       of += nf;
       if (!msg.empty() && verdict.empty()) verdict = "zkReLU layer " + to_string(i) + ": " + msg;
       verify_fc(i);

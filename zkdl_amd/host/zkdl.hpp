@@ -511,11 +511,19 @@ class zkReLU {
  protected:
   zk_relu* h_ = nullptr;
   uint n_ = 0;
+  uint kind_ = 0, shift_ = 0;   // additive: 0 = ReLU (the reference's only activation), 1 = LeakyReLU with negative slope 2^-shift (0: identity)
 
  public:
   zkReLU() { zkdl::check(zk_relu_create(zkdl::ctx(), &h_)); }
   zkReLU(const zkReLU&) = delete;   // the reference never copies it (raw owning pointers, demo.cu:103)
-  zkReLU(zkReLU&& o) noexcept : h_(o.h_), n_(o.n_) { o.h_ = nullptr; }
+  zkReLU(zkReLU&& o) noexcept : h_(o.h_), n_(o.n_), kind_(o.kind_), shift_(o.shift_) { o.h_ = nullptr; }
+  // additive: the activation this layer applies from its next operator() on
+  void set_activation(uint kind, uint shift) {
+    zkdl::check(zk_relu_set_activation(h_, kind, shift));
+    kind_ = kind;
+    shift_ = kind ? shift : 0;
+  }
+  bool leaky() const { return kind_ == 1; }
   ~zkReLU() { if (h_) zk_relu_destroy(h_); }
   FrTensor operator()(const FrTensor& X) {   // zkrelu.cu:44-51
     FrTensor out(X.size);
@@ -530,6 +538,12 @@ class zkReLU {
     auto u_r_bin = random_vec(log_size + 4), v_r_bin = random_vec(log_size + 4);
     auto u_recover = random_vec(log_size);
     auto u_hp = random_vec(log_size), v_hp = random_vec(log_size);
+    if (kind_ == 1) {   // additive: one more Hadamard sumcheck for the negative branch (zk_leaky_prove)
+      auto u_lk = random_vec(log_size), v_lk = random_vec(log_size);
+      zkdl::check(zk_leaky_prove(zkdl::ctx(), h_, X.gpu_data, Z.gpu_data, X.size, u_z_bin.data(), v_z_bin.data(), u_r_bin.data(), v_r_bin.data(), u_recover.data(),
+                                 u_hp.data(), v_hp.data(), u_lk.data(), v_lk.data(), zkdl::transcript()));
+      return;
+    }
     zkdl::check(zk_relu_prove(zkdl::ctx(), h_, X.gpu_data, Z.gpu_data, X.size, u_z_bin.data(), v_z_bin.data(), u_r_bin.data(), v_r_bin.data(), u_recover.data(),
                               u_hp.data(), v_hp.data(), zkdl::transcript()));
   }
@@ -539,6 +553,14 @@ class zkReLU {
     if (ch.size() != 7) throw std::runtime_error("Incompatible dimensions");
     int ok = 0;
     zkdl::check(zk_verify_relu(zkdl::ctx(), n, ch[0].data(), ch[1].data(), ch[2].data(), ch[3].data(), ch[5].data(), ch[6].data(), fr, n_fr, claims5, &ok));
+    return ok ? std::string() : std::string(zk_last_error(zkdl::ctx()));
+  }
+  // the same for a LeakyReLU slice (nine vectors: the seven above, then u_lk, v_lk); claims8 = the ReLU's five + (low o nsign)~, low~, nsign~
+  static std::string verify_leaky(uint n, const std::vector<std::vector<Fr_t>>& ch, const Fr_t* fr, size_t n_fr, Fr_t* claims8 = nullptr) {
+    if (ch.size() != 9) throw std::runtime_error("Incompatible dimensions");
+    int ok = 0;
+    zkdl::check(zk_verify_leaky(zkdl::ctx(), n, ch[0].data(), ch[1].data(), ch[2].data(), ch[3].data(), ch[5].data(), ch[6].data(), ch[7].data(), ch[8].data(), fr, n_fr,
+                                claims8, &ok));
     return ok ? std::string() : std::string(zk_last_error(zkdl::ctx()));
   }
 };

@@ -23,13 +23,33 @@ def save_tensor(t, fn):
     torch.jit.script(m).save(fn)
 
 
-def build(dims, seed, bias=False):
+def activation(spec):
+    """relu (the reference's model.py) | leaky:<s> (nn.LeakyReLU with negative slope 2^-s) | identity (nn.Identity) | none (no module at all)"""
+    if spec == "relu":
+        return nn.ReLU()
+    if spec.startswith("leaky:"):
+        return nn.LeakyReLU(2.0 ** -int(spec.split(":")[1]))
+    if spec == "identity":
+        return nn.Identity()
+    if spec == "none":
+        return None
+    raise ValueError("unknown activation " + spec)
+
+
+def build(dims, seed, bias=False, acts=("relu",)):
+    """acts: one spec for every hidden layer, or a single one for all of them"""
     torch.manual_seed(seed)
     layers = []
+    n_hidden = len(dims) - 2
+    acts = list(acts) * n_hidden if len(acts) == 1 else list(acts)
+    if len(acts) != n_hidden:
+        raise ValueError("need %d activation specs" % n_hidden)
     for i, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
         layers.append(nn.Linear(a, b, bias=bias))
         if i + 2 < len(dims):
-            layers.append(nn.ReLU())
+            m = activation(acts[i])
+            if m is not None:
+                layers.append(m)
     return nn.Sequential(*layers).eval()
 
 
@@ -39,11 +59,13 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--bias", action="store_true", help="Linear layers with bias (the reference's model.py has none; the demo's loader folds them into the matrices)")
+    ap.add_argument("--act", default="relu", help="hidden activations, one spec or a comma-separated list (one per hidden layer): relu | leaky:<s> (negative slope "
+                    "2^-s) | identity | none (consecutive Linear layers); the reference's model.py has ReLU only")
     ap.add_argument("--out-dir", default=".")
     args = ap.parse_args()
     dims = [int(x) for x in args.dims.split(",")]
     os.makedirs(args.out_dir, exist_ok=True)
-    model = build(dims, args.seed, args.bias)
+    model = build(dims, args.seed, args.bias, tuple(args.act.split(",")))
     x = torch.randn(args.batch, dims[0])
     with torch.no_grad():
         y = model(x)
