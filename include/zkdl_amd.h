@@ -317,6 +317,24 @@ int zk_verify_relu(zk_ctx* ctx, uint32_t n, const zk_fr* u_z_h, const zk_fr* v_z
 int zk_fs_derive(const uint8_t* seed32, uint32_t layer, uint32_t kind, uint32_t vec, uint32_t len, zk_fr* out_h);
 int zk_sha256(const void* data, size_t len, uint8_t* out32);
 
+/* ---------------------------------------------------------------- activation commitments inside the proof
+ * The reference's "commitment of activations / proof compression" future work (README.md:131-135).  With Z_i and A_i committed row-wise over
+ * layer i's generators (zk_commit), the three activation-side claims of a hidden layer -- Z_i~(p1), p1 = u_out || u_bs (zkFC_i); Z_i~(p2), p2 = v_hp
+ * (zkReLU_i); A_i~(p3), p3 = u_in || u_bs (zkFC_{i+1}) -- are reduced to ONE evaluation of the concatenated tensor T = [Z_i ; A_i] by an inner-product
+ * sumcheck against the public table E = [eq(p1,.) + alpha eq(p2,.) ; alpha^2 eq(p3,.)] (k + 1 rounds, k = log2 n), and T~(r') is opened ONCE against
+ * the concatenated commitment [com(Z_i) ; com(A_i)].  n = B_p * out_p entries per tensor (a power of two, a multiple of the generator count);
+ * pts_h = p1 | p2 | p3 (k each), alpha_h one challenge, fold_h the k + 1 round challenges (= the opening point).  Appends
+ *   Fr: [sumcheck 3 (k + 1) + 2][t(0)]   G1: [com(u_hi)][me_open 3 log2(n_gens) + 1]
+ * to tr; the opening's MSMs join the transcript's deferred batch (com(u_hi) is computed as the commitment of the row-folded tensor: the prover
+ * holds the tensor, and the generators' window tables exist).  One sumcheck and one opening per hidden layer instead of three openings. */
+int zk_act_open(zk_ctx* ctx, zk_gens* gens, const zk_fr* z_d, const zk_fr* a_d, uint32_t n, const zk_fr* pts_h, const zk_fr* alpha_h, const zk_fr* fold_h,
+                zk_transcript* tr);
+/* The verifier's side: com_d = the 2m points [com(Z_i) ; com(A_i)] (device), y_h = the three claimed evaluations as the layer proofs state them,
+ * fr_h / g1_h / inf_h the slice zk_act_open appended (G1 affine-canonical).  Checks the sumcheck, E~(r') (public arithmetic), T~(r') == t(0), and the
+ * opening with the checks of zk_verify_open. */
+int zk_verify_act_open(zk_ctx* ctx, zk_gens* gens, const zk_g1j* com_d, uint32_t m2, uint32_t k, const zk_fr* pts_h, const zk_fr* alpha_h, const zk_fr* fold_h,
+                       const zk_fr* y_h, const zk_fr* fr_h, size_t n_fr, const zk_g1a* g1_h, const uint8_t* inf_h, size_t n_g1, int* ok);
+
 /* ---------------------------------------------------------------- round-by-round Fiat-Shamir ("sound mode")
  * zk_fc_prove / zk_relu_prove take every challenge as an argument, like the reference's pre-drawn coins (proof.cu:3-11): that is the
  * reference-parity interface, and with zk_fs_derive a reproducible public-coin schedule -- but a prover who knows round r's challenge

@@ -1,0 +1,143 @@
+"""Activation commitments inside the proof (csrc/act_open.hip): the three activation-side claims of a hidden layer are reduced
+to one evaluation of [Z_i ; A_i] by an inner-product sumcheck and opened ONCE; the openings' MSMs run in the proof's deferred batch."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def zk():
+    from zkdl_amd.capi import MSM_PIPPENGER, Zk
+    z = Zk(0)
+    z.set_msm_mode(MSM_PIPPENGER)
+    yield z
+    z.close()
+
+
+def concat_coms(zk, gens, Z, A):
+    """[com(Z_i) ; com(A_i)] per hidden layer (the public activation commitments)"""
+    out = []
+    for g, z, a in zip(gens, Z, A):
+        out.append(zk.upload(np.concatenate([zk.commit(g, z).download(), zk.commit(g, a).download()])))
+    return out
+
+
+@pytest.mark.parametrize("dims,batch,derive", [([16, 32, 24, 8], 4, 0), ([16, 32, 24, 8], 4, 1), ([40, 70, 30], 20, 1), ([6, 5, 4], 3, 0)])
+def test_activation_openings_inside_the_proof(zk, oracle, dims, batch, derive):
+    import bigint_model as bm
+    from mlp_util import enqueue_proof, setup_mlp_gpu, synth_mlp
+    from zkdl_amd.capi import Transcript
+    from zkdl_amd.proof import (act_open_lengths, fs_challenges, parse_transcript, prove_activation_openings, statement_digest, verify_mlp,
+                                verify_mlp_with_activation_openings)
+    model = synth_mlp(oracle, dims, batch, seed=51)
+    st = setup_mlp_gpu(zk, model)
+    coms = [fc.com() for fc in st["fcs"]]
+    seed = statement_digest(zk, dims, batch, st["gens"], coms, st["X"], st["Yhat"])
+    chal = fs_challenges(seed, dims, batch)
+    act_coms = concat_coms(zk, st["gens"], st["Z"], st["A"])
+    zk.set_flag("derive_rounds", derive)
+    try:
+        tr = Transcript(zk)
+        enqueue_proof(st, chal, tr)
+        base_counts = None
+        prove_activation_openings(zk, dims, batch, st["gens"], st["Z"], st["A"], chal, seed, tr)
+        blob = tr.serialize()
+        # the same through a sealed (pipelined) submission
+        tr2 = Transcript(zk)
+        enqueue_proof(st, chal, tr2)
+        prove_activation_openings(zk, dims, batch, st["gens"], st["Z"], st["A"], chal, seed, tr2)
+        tr2.seal()
+        assert tr2.serialize() == blob
+    finally:
+        zk.set_flag("derive_rounds", 0)
+    args = (zk, dims, batch, st["gens"], coms, act_coms, st["X"], st["Yhat"])
+    ok, msg, remaining = verify_mlp_with_activation_openings(*args, blob)
+    assert ok, msg
+    L = len(dims) - 1
+    assert len(remaining) == 4 * (L - 1)              # per ReLU: mag_bin~, rem_bin~, (Z.sign)~, sign~ -- what the reference's ReLU leaves unbound
+    fr, aff, inf = parse_transcript(blob)
+    lens = act_open_lengths(dims, batch)
+    nf_act = sum(a for a, _ in lens)
+    # the opened value IS the random combination of the two tensors at the reduction's point (big-integer model on the downloaded tensors)
+    from zkdl_amd.proof import act_open_challenges
+    off = fr.shape[0] - nf_act
+    for i, (alpha, fold) in enumerate(act_open_challenges(seed, dims, batch)):
+        nf = lens[i][0]
+        t0 = bm.fr_from_mont(fr[off + nf - 1])
+        r = [bm.fr_from_mont(x) for x in fold]
+        zt = [bm.fr_from_mont(x) for x in st["Z"][i].download()]
+        at = [bm.fr_from_mont(x) for x in st["A"][i].download()]
+        want = ((1 - r[-1]) * bm.mle(zt, r[:-1]) + r[-1] * bm.mle(at, r[:-1])) % bm.R_MOD
+        assert t0 == want, i
+        off += nf
+    # tampering: every Fr value of the openings' slices, a G1 coordinate of each, a swapped commitment, a false layer claim
+    rng = np.random.default_rng(4)
+    n_fr, n_g1 = fr.shape[0], aff.shape[0]
+    for idx in range(n_fr - nf_act, n_fr):
+        bad = bytearray(blob)
+        bad[24 + 32 * idx + int(rng.integers(0, 32))] ^= 1 << int(rng.integers(0, 8))
+        assert not verify_mlp_with_activation_openings(*args, bytes(bad))[0], idx
+    ng_act = sum(b for _, b in lens)
+    for idx in range(n_g1 - ng_act, n_g1, 3):
+        bad = bytearray(blob)
+        bad[24 + 32 * n_fr + 96 * idx + int(rng.integers(0, 96))] ^= 1 << int(rng.integers(0, 8))
+        assert not verify_mlp_with_activation_openings(*args, bytes(bad))[0], idx
+    if L >= 3:
+        swapped = [act_coms[1], act_coms[0]] + act_coms[2:]
+        if swapped[0].n == act_coms[0].n:
+            assert not verify_mlp_with_activation_openings(zk, dims, batch, st["gens"], coms, swapped, st["X"], st["Yhat"], blob)[0]
+    # a commitment to a different tensor: the opening no longer matches
+    other = [zk.upload(np.concatenate([zk.commit(st["gens"][0], st["A"][0]).download(), zk.commit(st["gens"][0], st["Z"][0]).download()]))] + act_coms[1:]
+    assert not verify_mlp_with_activation_openings(zk, dims, batch, st["gens"], coms, other, st["X"], st["Yhat"], blob)[0]
+
+
+def test_activation_openings_at_full_size(zk):
+    """18M-parameter MLP, batch 256: 7 claim reductions + 7 openings of 2^20-entry tensors recorded into the proof; verifies; cost printed."""
+    import time
+    import bench
+    from zkdl_amd.capi import Transcript
+    from zkdl_amd.proof import fs_challenges, prove_activation_openings, statement_digest, verify_mlp_with_activation_openings
+    dims, batch = bench.WORKLOADS["mlp18m_b256"]
+    wl = bench.Workload(zk, dims, batch, seed=21)
+    coms = [fc.com() for fc in wl.fcs]
+    seed = statement_digest(zk, dims, batch, wl.gens, coms, wl.X, wl.Yhat)
+    chal = fs_challenges(seed, dims, batch)
+    zk.sync()
+    t0 = time.perf_counter()
+    act_coms = concat_coms(zk, wl.gens[:-1], wl.Z, wl.A)
+    zk.sync()
+    t_commit = (time.perf_counter() - t0) * 1e3
+    zk.set_flag("derive_rounds", 1)
+    try:
+        tr = Transcript(zk)
+        times = {}
+        for with_act in (0, 1, 0, 1):
+            zk.sync()
+            t0 = time.perf_counter()
+            for rep in range(3):
+                wl.prove(chal, tr)
+                if with_act:
+                    prove_activation_openings(zk, dims, batch, wl.gens, wl.Z, wl.A, chal, seed, tr)
+                tr.flush()
+            zk.sync()
+            times[with_act] = (time.perf_counter() - t0) * 1e3 / 3
+        blob = tr.serialize()
+    finally:
+        zk.set_flag("derive_rounds", 0)
+    print("activation openings inside the proof, 18M MLP batch 256 (synchronous proofs): %.2f ms per proof without, %.2f ms with 7 reductions + 7 openings; "
+          "14 activation commitments (2^18-2^19 entries each, incl. the host round trips of this test): %.1f ms" % (times[0], times[1], t_commit))
+    ok, msg, remaining = verify_mlp_with_activation_openings(zk, dims, batch, wl.gens, coms, act_coms, wl.X, wl.Yhat, blob, chal=chal)
+    assert ok, msg
+    assert len(remaining) == 4 * 7
+    bad = bytearray(blob)
+    bad[-200] ^= 1
+    assert not verify_mlp_with_activation_openings(zk, dims, batch, wl.gens, coms, act_coms, wl.X, wl.Yhat, bytes(bad), chal=chal)[0]
+    tr.close()

@@ -34,7 +34,7 @@ zk_fc_out zk_fc_com_size zk_fc_weights zk_fc_com zk_fc_load_input zk_fc_forward 
 zk_relu_destroy zk_relu_forward zk_relu_sign zk_relu_mag_bin zk_relu_rem_bin zk_relu_prove zk_transcript_create
 zk_transcript_destroy zk_transcript_reset zk_transcript_flush zk_transcript_counts zk_transcript_read zk_transcript_read_affine
 zk_transcript_digest zk_transcript_digest_dev zk_transcript_serialize zk_transcript_seal zk_transcript_seal_pair zk_transcript_stream
-zk_verify_fc zk_verify_relu zk_verify_open zk_fs_derive zk_sha256 zk_fc_prove_fs zk_relu_prove_fs zk_fs_round_challenges zk_relu_set_activation zk_leaky_prove zk_verify_leaky""".split()
+zk_verify_fc zk_verify_relu zk_verify_open zk_fs_derive zk_sha256 zk_fc_prove_fs zk_relu_prove_fs zk_fs_round_challenges zk_relu_set_activation zk_leaky_prove zk_verify_leaky zk_act_open zk_verify_act_open""".split()
 
 
 class ZkError(RuntimeError):
@@ -480,6 +480,30 @@ class Zk:
         self._chk(self.lib.zk_verify_leaky(self.ctx, _u32(n), *[_hp(_fr_host(ch[i])) for i in (0, 1, 2, 3, 5, 6, 7, 8)], _hp(fr), _sz(fr.shape[0]), _hp(claims),
                                            ctypes.byref(ok)))
         return bool(ok.value), ("" if ok.value else self.lib.zk_last_error(self.ctx).decode()), claims
+
+    def act_open(self, gens, z, a, pts, alpha, fold, tr):
+        """zk_act_open: the three activation-side claims of a hidden layer reduced to one opening of [Z ; A], recorded into tr."""
+        if z.n != a.n:
+            raise ShapeError(ZK_ERR_SHAPE, "Incompatible dimensions")
+        k = self.ceil_log2(z.n)
+        pts = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.uint32).reshape(-1, 8) for p in pts]), dtype=np.uint32)
+        fold = np.ascontiguousarray(fold, dtype=np.uint32).reshape(-1, 8)
+        if pts.shape[0] != 3 * k or fold.shape[0] != k + 1:
+            raise ShapeError(ZK_ERR_SHAPE, "Incompatible dimensions")
+        self._chk(self.lib.zk_act_open(self.ctx, gens.h, _vp(z.ptr), _vp(a.ptr), _u32(z.n), _hp(_fr_host(pts)), _hp(_fr_host(alpha, 1)), _hp(fold), tr.h))
+
+    def verify_act_open(self, gens, com2, k, pts, alpha, fold, ys, fr, aff, inf):
+        """zk_verify_act_open: com2 = DevArray of the 2m points [com(Z) ; com(A)]."""
+        pts = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.uint32).reshape(-1, 8) for p in pts]), dtype=np.uint32)
+        fold = np.ascontiguousarray(fold, dtype=np.uint32).reshape(-1, 8)
+        ys = np.ascontiguousarray(np.asarray(ys, dtype=np.uint32).reshape(3, 8))
+        fr = np.ascontiguousarray(fr, dtype=np.uint32).reshape(-1, 8)
+        aff = np.ascontiguousarray(aff, dtype=np.uint32).reshape(-1, 24)
+        inf = np.ascontiguousarray(inf, dtype=np.uint8).reshape(-1)
+        ok = ctypes.c_int(0)
+        self._chk(self.lib.zk_verify_act_open(self.ctx, gens.h, _vp(com2.ptr), _u32(com2.n), _u32(k), _hp(_fr_host(pts)), _hp(_fr_host(alpha, 1)), _hp(fold), _hp(ys),
+                                              _hp(fr), _sz(fr.shape[0]), _hp(aff), _hp(inf), _sz(aff.shape[0]), ctypes.byref(ok)))
+        return bool(ok.value), ("" if ok.value else self.lib.zk_last_error(self.ctx).decode())
 
     # ---- layers
     def float_to_fr(self, fs_d, rows, rows_p, cols, cols_p):

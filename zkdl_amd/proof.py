@@ -269,3 +269,85 @@ def claimed_activation_values(dims, open_claims):
         else:
             out.append(by["relu_%d:Z~(v_hp)" % i])
     return out
+
+
+# ------------------------------------------------------------------ activation openings INSIDE the proof, one per hidden layer (csrc/act_open.hip)
+KIND_ACT = 2
+
+
+def act_open_challenges(seed, dims, batch):
+    """Per hidden layer i: (alpha, fold) -- the combination challenge of its three claims and the k + 1 round challenges of the claim-reduction
+    sumcheck (= the opening point); statement-derived like every other challenge of the throughput mode."""
+    sh = layer_shapes(dims)
+    kb = ceil_log2(1 << ceil_log2(batch))
+    out = []
+    for i in range(len(sh) - 1):
+        k = kb + ceil_log2(sh[i]["out_p"])
+        out.append((fs_derive(seed, i, KIND_ACT, 0, 1), fs_derive(seed, i, KIND_ACT, 1, k + 1)))
+    return out
+
+
+def act_claim_points(dims, chal):
+    """Per hidden layer i: (p1, p2, p3) -- Z_i is claimed at p1 = u_out || u_bs by zkFC_i and at p2 = v_hp by zkReLU_i, A_i at p3 = u_in || u_bs by zkFC_{i+1}."""
+    L = len(dims) - 1
+    by = {(kind, i): ch for kind, i, ch in chal}
+    out = []
+    for i in range(L - 1):
+        fc, relu, nxt = by[("fc", i)], by[("relu", i)], by[("fc", i + 1)]
+        out.append((np.concatenate([fc[2], fc[0]]), relu[6], np.concatenate([nxt[1], nxt[0]])))
+    return out
+
+
+def prove_activation_openings(zk, dims, batch, gens, Z, A, chal, seed, tr):
+    """Behind the layer proofs already recorded on `tr`: one claim-reduction sumcheck and ONE opening of [Z_i ; A_i] per hidden layer
+    (zk_act_open); their MSMs join the transcript's deferred batch."""
+    pts = act_claim_points(dims, chal)
+    for i, (alpha, fold) in enumerate(act_open_challenges(seed, dims, batch)):
+        zk.act_open(gens[i], Z[i], A[i], pts[i], alpha, fold, tr)
+
+
+def act_open_lengths(dims, batch):
+    """(n_fr, n_g1) of every layer's zk_act_open slice"""
+    sh = layer_shapes(dims)
+    kb = ceil_log2(1 << ceil_log2(batch))
+    return [(3 * (kb + ceil_log2(s["out_p"]) + 1) + 3, 3 * ceil_log2(s["n_gens"]) + 2) for s in sh[:-1]]
+
+
+def verify_mlp_with_activation_openings(zk, dims, batch, gens, coms, act_coms, x_fr, y_fr, blob, chal=None):
+    """Verify the layer proofs AND the activation openings behind them.  act_coms[i] = DevArray of the 2m points [com(Z_i) ; com(A_i)] (public, like
+    the weight commitments).  What verify_mlp returns as open claims on Z_i / A_i is now bound to those commitments; what stays open is what the
+    reference's ReLU leaves unbound (bit tensors, sign).  Returns (ok, message, remaining open claims)."""
+    sh = layer_shapes(dims)
+    L = len(sh)
+    seed = statement_digest(zk, dims, batch, gens, coms, x_fr, y_fr)
+    if chal is None:
+        chal = fs_challenges(seed, dims, batch)
+    try:
+        fr, aff, inf = parse_transcript(blob)
+    except ValueError as e:
+        return False, str(e), []
+    lens = act_open_lengths(dims, batch)
+    nf_act, ng_act = sum(a for a, _ in lens), sum(b for _, b in lens)
+    if fr.shape[0] < nf_act or aff.shape[0] < ng_act:
+        return False, "transcript does not have the shape of this model's proof", []
+    nf0, ng0 = fr.shape[0] - nf_act, aff.shape[0] - ng_act
+    head = b"ZKDLTR01" + struct.pack("<QQ", nf0, ng0) + fr[:nf0].tobytes() + aff[:ng0].tobytes() + inf[:ng0].tobytes()
+    ok, msg, open_claims = verify_mlp(zk, dims, batch, gens, coms, x_fr, y_fr, head, chal=chal)
+    if not ok:
+        return False, msg, open_claims
+    by = {k: v for k, v in open_claims}
+    pts = act_claim_points(dims, chal)
+    kb = ceil_log2(1 << ceil_log2(batch))
+    of, og = nf0, ng0
+    closed = set()
+    for i, (alpha, fold) in enumerate(act_open_challenges(seed, dims, batch)):
+        nf, ng = lens[i]
+        ys = [by["Z_%d~(u_out||u_bs)" % i], by["relu_%d:Z~(v_hp)" % i], by["A_%d~(u_in||u_bs)" % i]]
+        k = kb + ceil_log2(sh[i]["out_p"])
+        ok, msg = zk.verify_act_open(gens[i], act_coms[i], k, pts[i], alpha, fold, ys, fr[of:of + nf], aff[og:og + ng], inf[og:og + ng])
+        if not ok:
+            return False, "activation opening, layer %d: %s" % (i, msg), open_claims
+        closed |= {"Z_%d~(u_out||u_bs)" % i, "relu_%d:Z~(v_hp)" % i, "A_%d~(u_in||u_bs)" % i}
+        of += nf
+        og += ng
+    return True, "", [(k, v) for k, v in open_claims if k not in closed]
