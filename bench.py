@@ -397,6 +397,7 @@ def main():
     ap.add_argument("--cpu-baseline", default="full", choices=["sample", "full", "off"], help="oracle timed on the whole prove loop at the bench's batch size (default: ~1 min on the "
                     "GPU box's host, nothing extrapolated), on a layer subset (extrapolated), or not at all; either way its outputs are compared with one GPU proof (parity_checked)")
     ap.add_argument("--steady-steps", type=int, default=120, help="proofs of the longer of the two untimed runs the steady-state figure is taken from (0 = skip)")
+    ap.add_argument("--ext-steps", type=int, default=24, help="proofs of the longer untimed run of each protocol extension (sound mode, activation openings); 0 = skip")
     ap.add_argument("--latency-reps", type=int, default=5, help="single proofs (nothing else in flight) timed for latency_ms_per_proof (0 = skip)")
     ap.add_argument("--no-msm-probe", action="store_true", help="skip the full-width 2^24-pair zk_msm_batch throughput probe")
     ap.add_argument("--spinup-ms", type=float, default=400.0, help="untimed proofs before the W warm-up steps until this much wall time has passed: the first process on a "
@@ -478,8 +479,10 @@ def main():
         lanes = torch.tensor(fr_to_lanes(pow(7, rank + 1, R_MOD) * (R_MOD - 1) % R_MOD), dtype=torch.int64)
         agg = allreduce_digest(lanes)
         dist.barrier()
+        seen = [None] * world
+        dist.all_gather_object(seen, rank)
         if rank == 0:
-            print(json.dumps({"selftest": True, "n_gpus": world, "collective_world_size": dist.get_world_size(), "aggregate_fr": hex(agg)}))
+            print(json.dumps({"selftest": True, "n_gpus": world, "collective_world_size": dist.get_world_size(), "aggregate_fr": hex(agg), "ranks": sorted(seen)}))
         dist.destroy_process_group()
         return
     if args.same_device:
@@ -656,6 +659,44 @@ def main():
             latency[name] = {"median_ms": float(np.median(ts)), "min_ms": float(min(ts)), "reps": len(ts)}
         zk.set_flag("derive_rounds", 1 if derive else 0)
         latency["definition"] = "one batch-%d proof, nothing else in flight: host wall time from the first prove call until its G1 phase has finished (demo.cu:124-140)" % batch
+    # ---- the two protocol extensions, same pipelined loop (untimed side measurements; --ext-steps 0 skips them):
+    #  * sound mode: every sumcheck round challenge from a hash of the rounds before it (zk_fc_prove_fs / zk_relu_prove_fs, csrc/fs_rounds.hip)
+    #  * activation openings inside the proof: per hidden layer one claim-reduction sumcheck + one opening of [Z_i ; A_i] (zk_act_open); the
+    #    14 activation commitments themselves are made once, outside (they are per-input setup, like inference)
+    extensions = None
+    if args.ext_steps > 0 and pipelined and not paired and args.msm == "pippenger":
+        from zkdl_amd.proof import (act_claim_points, act_open_challenges, fs_challenges, prove_mlp_fs, statement_digest)
+        coms_ = [fc.com() for fc in wl.fcs]
+        seed_ = statement_digest(zk, dims, batch, wl.gens, coms_, wl.X, wl.Yhat)
+        chal_ = fs_challenges(seed_, dims, batch)
+        pts_, ac_ = act_claim_points(dims, chal_), act_open_challenges(seed_, dims, batch)
+
+        def run_ext(n, which):
+            zk.sync()
+            t = time.perf_counter()
+            for j in range(n):
+                tr_ = wl.trs[j % len(wl.trs)]
+                if which == "fs":
+                    prove_mlp_fs(wl.fcs, wl.relus, wl.gens, wl.X, wl.Z, wl.A, wl.Yhat, seed_, tr_)
+                else:
+                    wl.prove(chal_, tr_)
+                    for i_, (alpha_, fold_) in enumerate(ac_):
+                        zk.act_open(wl.gens[i_], wl.Z[i_], wl.A[i_], pts_[i_], alpha_, fold_, tr_)
+                tr_.seal(extra_rows + 64 * (j % len(wl.trs)))
+            zk.sync()
+            return (time.perf_counter() - t) * 1e3
+
+        extensions = {}
+        for which in ("fs", "act"):
+            run_ext(len(wl.trs), which)                              # warm: bit tensors materialised, pools sized
+            n_short, n_long = max(2, args.ext_steps // 3), args.ext_steps
+            t_short, t_long = run_ext(n_short, which), run_ext(n_long, which)
+            one = [run_ext(1, which) for _ in range(3)]
+            extensions["sound_mode_round_by_round_fiat_shamir" if which == "fs" else "activation_openings_in_proof"] = {
+                "steady_state_ms_per_proof": (t_long - t_short) / (n_long - n_short), "latency_ms_per_proof": float(np.median(one)),
+                "runs_ms": {str(n_short): t_short, str(n_long): t_long}}
+        extensions["note"] = ("same workload, same pipelined loop as the headline (derive_rounds / g1_batch / inflight as configured); the headline itself is the "
+                              "reference-parity mode (pre-drawn challenges, no activation commitments), which is what the reference times")
     # ---- the proof the CPU oracle is compared with: made in the benchmarked configuration, with len(trs) proofs in flight around it
     parity_src = None
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_baseline != "off"
@@ -814,7 +855,7 @@ def main():
                       "warmup_drain_form_proofs": (min(2, args.warmup) if derive and args.warmup >= 2 else 0),
                       "schedule_note": "the last drain_form_proofs proofs of the timed region run every round commitment as an MSM (derive_rounds off): they have no later proof to hide the derivation under"},
            "ms_per_proof": ms_per_step, "steady_state_ms_per_proof": (steady["ms_per_proof"] if steady else None), "steady_state": steady,
-           "latency_ms_per_proof": (min(v["median_ms"] for v in latency.values() if isinstance(v, dict)) if latency else None), "latency": latency,
+           "latency_ms_per_proof": (min(v["median_ms"] for v in latency.values() if isinstance(v, dict)) if latency else None), "latency": latency, "extensions": extensions,
            "per_rank_ms_per_proof": per_rank_ms, "collective_world_size": (dist.get_world_size() if world > 1 else 1),
            "collective_backend": (dist.get_backend() if world > 1 else None), "rank_devices": rank_devices,
            "host_enqueue_ms_per_step": t_enq * 1e3 / max(args.steps, 1), "aggregate_fr": hex(aggregate), "setup": wl.info, "roofline": roofline,

@@ -355,6 +355,22 @@ int zk_fc_prove_fs(zk_ctx* ctx, zk_fc* fc, const zk_fr* x_d, uint32_t xn, const 
 int zk_relu_prove_fs(zk_ctx* ctx, const zk_relu* relu, const zk_fr* x_d, const zk_fr* z_d, uint32_t n, const uint8_t* seed32, uint32_t layer, zk_transcript* tr);
 int zk_fs_round_challenges(const uint8_t* seed32, uint32_t layer, uint32_t kind, uint32_t which, const zk_fr* coeffs_h, uint32_t k, zk_fr* out_h);
 
+/* ---------------------------------------------------------------- multi-GPU: the run aggregate, natively over RCCL / xGMI
+ * One process per GPU, independent proof batches per rank, no data-path collective (north_star); the only exchange is ONE all-reduce of the
+ * per-rank aggregate -- the sum of the digests (8 zero-extended 64-bit lanes each, zk_transcript_seal / zk_transcript_digest_dev) of the rank's
+ * proofs.  These entry points let a C / C++ host do that without torch.distributed (bench.py uses torch.distributed's RCCL backend for the same
+ * all-reduce).  librccl is dlopen'ed by zk_dist_unique_id / zk_dist_init; nothing else in the library needs it.  The reference has no multi-GPU path.
+ *   rank 0: zk_dist_unique_id(id) and hand the 128 bytes to the other ranks (file, environment, MPI ...); every rank: zk_dist_init(ctx, rank, world, id, &d);
+ *   per run: zk_dist_sum_rows(ctx, rows_d, n_proofs, agg_d); zk_dist_allreduce_u64(d, agg_d, 8); copy agg to the host; zk_dist_lanes_to_fr. */
+typedef struct zk_dist zk_dist;
+int zk_dist_unique_id(uint8_t* id128);
+int zk_dist_init(zk_ctx* ctx, int rank, int world, const uint8_t* id128, zk_dist** out);
+int zk_dist_world_size(const zk_dist* d);                                   /* as RCCL reports it */
+int zk_dist_sum_rows(zk_ctx* ctx, const uint64_t* rows_d, size_t n, uint64_t* out8_d);   /* waits for every sealed proof first */
+int zk_dist_allreduce_u64(zk_dist* d, uint64_t* lanes_d, size_t n);           /* in place, ncclSum on ncclUint64; returns when done */
+int zk_dist_lanes_to_fr(const uint64_t* lanes8_h, zk_fr* out_h);              /* sum_j lane_j 2^(32 j) mod r, raw limbs */
+int zk_dist_destroy(zk_dist* d);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,7 +60,7 @@ def _run_bench(*argv):
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, env=env, timeout=300)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_bench_launches_its_own_ranks(world):
     """`python bench.py --gpus N` as the driver invokes it (no WORLD_SIZE): the parent spawns N ranks, rank 0's
     JSON line comes back on stdout, and the ranks see each other (gloo here; the collective path on CPU)."""
@@ -72,6 +72,7 @@ def test_bench_launches_its_own_ranks(world):
     rec = json.loads(lines[0])
     want = sum(pow(7, r + 1, R_MOD) * (R_MOD - 1) % R_MOD for r in range(world)) % R_MOD
     assert rec["n_gpus"] == world and rec["collective_world_size"] == world and int(rec["aggregate_fr"], 16) == want
+    assert rec["ranks"] == list(range(world))               # every rank reported in (world 8: the driver's scaling run's process layout)
 
 
 def test_bench_launcher_propagates_a_dead_rank():
@@ -109,3 +110,19 @@ def test_shard_rank_weights_are_the_eq_polynomial():
     uv = [_to_int(x) for x in u]
     assert ws[5] == uv[0] * (1 - uv[1]) * uv[2] % R_MOD           # rank 5 = bits (1, 0, 1), LSB first
     assert _to_int(eq_weight(u[:0], 0)) == 1 and _to_int(_to_mont(12345)) == 12345
+
+
+def test_native_lanes_to_fr_matches_the_python_reduction():
+    """zk_dist_lanes_to_fr (host code of the native RCCL path: carry-propagate 8 summed 64-bit lanes, reduce mod r) against zkdl_amd.dist.lanes_to_fr."""
+    import ctypes
+    import numpy as np
+    from zkdl_amd.capi import load_library
+    from zkdl_amd.dist import lanes_to_fr
+    lib = load_library()
+    rng = np.random.default_rng(12)
+    cases = [rng.integers(0, 1 << 63, size=8, dtype=np.uint64) for _ in range(50)]
+    cases += [np.zeros(8, np.uint64), np.full(8, (1 << 64) - 1, dtype=np.uint64), np.array([1, 0, 0, 0, 0, 0, 0, 0], np.uint64)]
+    for lanes in cases:
+        out = np.zeros(8, np.uint32)
+        assert lib.zk_dist_lanes_to_fr(lanes.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)) == 0
+        assert int.from_bytes(out.tobytes(), "little") == lanes_to_fr([int(x) for x in lanes])

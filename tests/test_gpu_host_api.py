@@ -231,3 +231,19 @@ def test_demo_loads_leaky_identity_and_bare_linear_stacks(tmp_path):
                     "nn.Linear(5, 4, bias=False)).eval(); x = torch.randn(3, 6); M.save_tensor(x, '%s/x.pt'); torch.jit.trace(m, x[:1]).save('%s/m.pt')" % (d, d)], check=True, cwd=ROOT)
     bad = subprocess.run([exe, os.path.join(d, "m.pt"), os.path.join(d, "x.pt")], capture_output=True, text=True, cwd=d, timeout=600)
     assert bad.returncode != 0 and "not a power of two" in (bad.stdout + bad.stderr)
+
+
+def test_demo_aggregates_over_rccl_without_torch(tmp_path):
+    """The native collective of the multi-GPU path (zk_dist_*: dlopen'ed librccl, ncclAllReduce of the digest lanes on the context's stream) through
+    the C++ driver, with the one rank a 1-GPU box has: the aggregate over 1 rank is that rank's transcript digest.  (More ranks need more devices:
+    RCCL refuses two ranks on one GPU; `demo --gpus N` starts one process per device.)"""
+    exe = os.path.join(HOST, "demo")
+    if not os.path.exists(exe):
+        pytest.skip("zkdl_amd/host/demo not built (needs LibTorch)")
+    d = str(tmp_path)
+    subprocess.run([sys.executable, "-m", "zkdl_amd.model", "--dims", "12,20,9,7", "--batch", "5", "--seed", "3", "--out-dir", d], check=True, cwd=ROOT)
+    run = subprocess.run([exe, os.path.join(d, "traced_model.pt"), os.path.join(d, "sample_input.pt"), "--seed", "9", "--dist"], capture_output=True, text=True, cwd=d, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    digest = run.stdout.split("digest ")[1].split()[0]
+    line = [ln for ln in run.stdout.splitlines() if ln.startswith("Aggregate over 1 ranks")]
+    assert line and line[0].split(": ")[-1].strip() == digest

@@ -4,7 +4,7 @@ out=gpurun_out/ab_g1batch.txt
 : > $out
 run() {  # label, extra flags..., env
   label=$1; shift
-  python3 bench.py --cpu-baseline off --no-msm-probe --steady-steps 0 --latency-reps 3 --prof-steps 1 --steps 60 --warmup 6 "$@" > gpurun_out/ab_tmp.json 2>> gpurun_out/ab_err.log
+  python3 bench.py --cpu-baseline off --no-msm-probe --steady-steps 0 --ext-steps 0 --latency-reps 3 --prof-steps 1 --steps 60 --warmup 6 "$@" > gpurun_out/ab_tmp.json 2>> gpurun_out/ab_err.log
   python3 - "$label" <<'PY' >> gpurun_out/ab_g1batch.txt
 import json, sys
 d = json.load(open("gpurun_out/ab_tmp.json"))

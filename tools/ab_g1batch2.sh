@@ -4,7 +4,7 @@ out=gpurun_out/ab_g1batch2.txt
 : > $out
 run() {
   label=$1; shift
-  python3 bench.py --cpu-baseline off --no-msm-probe --steady-steps 0 --latency-reps 0 --prof-steps 1 --steps 60 --warmup 6 "$@" > gpurun_out/ab_tmp.json 2>> gpurun_out/ab_err.log
+  python3 bench.py --cpu-baseline off --no-msm-probe --steady-steps 0 --ext-steps 0 --latency-reps 0 --prof-steps 1 --steps 60 --warmup 6 "$@" > gpurun_out/ab_tmp.json 2>> gpurun_out/ab_err.log
   python3 - "$label" <<'PY' >> gpurun_out/ab_g1batch2.txt
 import json, sys
 d = json.load(open("gpurun_out/ab_tmp.json"))

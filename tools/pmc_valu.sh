@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 i=0
 for v in "$@"; do
   i=$((i+1)); out=$PWD/gpurun_out/pmcv_$i; rm -rf $out; mkdir -p $out
-  ( [ -n "$v" ] && export $v; timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $out -o pmc -- python3 bench.py --cpu-baseline off --no-msm-probe --no-prewarm --steady-steps 0 --latency-reps 0 --spinup-ms 0 --serial --steps 2 --warmup 1 > $out/log 2>&1 )
+  ( [ -n "$v" ] && export $v; timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $out -o pmc -- python3 bench.py --cpu-baseline off --no-msm-probe --no-prewarm --steady-steps 0 --ext-steps 0 --latency-reps 0 --spinup-ms 0 --serial --steps 2 --warmup 1 > $out/log 2>&1 )
   python3 - "$out" "$v" <<'PY'
 import csv, glob, sys, collections
 out, tag = sys.argv[1], sys.argv[2]

@@ -34,7 +34,8 @@ zk_fc_out zk_fc_com_size zk_fc_weights zk_fc_com zk_fc_load_input zk_fc_forward 
 zk_relu_destroy zk_relu_forward zk_relu_sign zk_relu_mag_bin zk_relu_rem_bin zk_relu_prove zk_transcript_create
 zk_transcript_destroy zk_transcript_reset zk_transcript_flush zk_transcript_counts zk_transcript_read zk_transcript_read_affine
 zk_transcript_digest zk_transcript_digest_dev zk_transcript_serialize zk_transcript_seal zk_transcript_seal_pair zk_transcript_stream
-zk_verify_fc zk_verify_relu zk_verify_open zk_fs_derive zk_sha256 zk_fc_prove_fs zk_relu_prove_fs zk_fs_round_challenges zk_relu_set_activation zk_leaky_prove zk_verify_leaky zk_act_open zk_verify_act_open""".split()
+zk_verify_fc zk_verify_relu zk_verify_open zk_fs_derive zk_sha256 zk_fc_prove_fs zk_relu_prove_fs zk_fs_round_challenges zk_relu_set_activation zk_leaky_prove zk_verify_leaky zk_act_open zk_verify_act_open zk_dist_unique_id zk_dist_init zk_dist_world_size zk_dist_sum_rows zk_dist_allreduce_u64
+zk_dist_lanes_to_fr zk_dist_destroy""".split()
 
 
 class ZkError(RuntimeError):
@@ -77,7 +78,18 @@ def _header_prototypes():
     return protos
 
 
+_LIB = None
+
+
 def load_library():
+    """The shared library with its prototypes set (loaded once per process)."""
+    global _LIB
+    if _LIB is None:
+        _LIB = _load_library()
+    return _LIB
+
+
+def _load_library():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libzkdl_amd.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                            "there is no CPU fallback for the proving path")

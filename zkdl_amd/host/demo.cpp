@@ -1,5 +1,5 @@
 // zkdl_amd/host/demo.cpp -- the reference driver (demo.cu) on the MI355X library.
-//   ./demo traced_model.pt sample_input.pt [--seed S] [--dump DIR] [--fs] [--verify] [--repeat N]
+//   ./demo traced_model.pt sample_input.pt [--seed S] [--dump DIR] [--fs] [--verify] [--repeat N] [--gpus N] [--dist]
 // Same CLI, same inputs (TorchScript nn.Sequential of bias-free Linear + ReLU; a tensor saved as
 // parameter "0" of a scripted empty module, model.py:4-8), same outputs: demo.out (Y_hat, one
 // 0x%064x per line, demo.cu:119-122) and the three stdout lines (demo.cu:92,140-141).
@@ -12,11 +12,21 @@
 // only public data (generators, commitments, the input and output tensors), and prints "Verification: OK" or the failed check.
 // --repeat N proves the same statement N more times after the reference's single (cold: first-use allocations, window tables)
 // timed loop and prints the best of them as "Warm proof time: ..." -- the transcript kept is the first run's.
+// --gpus N (N > 1): this process starts N copies of itself, one per GPU (ZKDL_RANK / ZKDL_WORLD / ZKDL_DEVICE in their environment), BEFORE it
+// touches the GPU; every rank proves the statement on its own device with its own generator seed (independent proof batches: north_star's
+// multi-GPU layout), and the ranks' transcript digests are summed by ONE RCCL all-reduce over xGMI (zk_dist_*: no torch.distributed); rank 0
+// prints "Aggregate over N ranks: ...".  The 128-byte RCCL id travels from rank 0 to the others through a file.  --dist runs the same
+// collective path with a single rank (what a 1-GPU box can exercise).
 #include <torch/script.h>
 #include <torch/torch.h>
 
 #include <algorithm>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <chrono>
 #include <cmath>
+#include <thread>
 #include <cstring>
 #include <fstream>
 #include <iterator>
@@ -151,18 +161,59 @@ vector<zkFC> load_model(const string& model_path, vector<unique_ptr<Commitment>>
   return fcs;
 }
 
+// --gpus N: the parent of the N ranks.  It never touches the GPU (the ranks are exec'ed copies of this program).
+static int spawn_ranks(int n, char* argv[]) {
+  char idfile[] = "/tmp/zkdl_rccl_id_XXXXXX";
+  int fd = mkstemp(idfile);
+  if (fd >= 0) close(fd);
+  unlink(idfile);   // rank 0 creates it (write to .tmp, rename): the others wait for it to appear
+  vector<pid_t> pids;
+  for (int r = 0; r < n; r++) {
+    pid_t pid = fork();
+    if (pid == 0) {
+      setenv("ZKDL_RANK", to_string(r).c_str(), 1);
+      setenv("ZKDL_WORLD", to_string(n).c_str(), 1);
+      if (!getenv("ZKDL_DIST_SAME_DEVICE")) setenv("ZKDL_DEVICE", to_string(r).c_str(), 1);
+      setenv("ZKDL_DIST_ID_FILE", idfile, 1);
+      setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
+      execv("/proc/self/exe", argv);
+      _exit(127);
+    }
+    pids.push_back(pid);
+  }
+  int rc = 0;
+  for (pid_t pid : pids) {
+    int st = 0;
+    waitpid(pid, &st, 0);
+    const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128;
+    if (code && !rc) rc = code;
+  }
+  unlink(idfile);
+  return rc;
+}
+
 int main(int argc, char* argv[]) {
   if (argc < 3) {
     cerr << "usage: demo traced_model.pt sample_input.pt [--seed S]\n";
     return 2;
   }
+  int gpus = 1;
+  bool dist = false;
+  for (int i = 3; i < argc; i++) {
+    if (string(argv[i]) == "--gpus" && i + 1 < argc) gpus = atoi(argv[i + 1]);
+    if (string(argv[i]) == "--dist") dist = true;
+  }
+  const char* rank_env = getenv("ZKDL_RANK");
+  if (gpus > 1 && !rank_env) return spawn_ranks(gpus, argv);
+  const int rank = rank_env ? atoi(rank_env) : 0, world = rank_env ? atoi(getenv("ZKDL_WORLD") ? getenv("ZKDL_WORLD") : "1") : 1;
+  dist = dist || world > 1;
   string dump_dir;
   vector<Fr_t> challenges;
   bool use_fs = false, do_verify = false;
   int repeat = 0;
   for (int i = 3; i < argc; i++) {
     if (string(argv[i]) == "--repeat" && i + 1 < argc) repeat = atoi(argv[i + 1]);
-    if (string(argv[i]) == "--seed" && i + 1 < argc) zkdl::seed(strtoull(argv[i + 1], nullptr, 0));
+    if (string(argv[i]) == "--seed" && i + 1 < argc) zkdl::seed(strtoull(argv[i + 1], nullptr, 0) + (uint64_t)rank);   // every rank its own generators
     if (string(argv[i]) == "--dump" && i + 1 < argc) dump_dir = argv[i + 1];
     if (string(argv[i]) == "--fs") use_fs = true;
     if (string(argv[i]) == "--verify") do_verify = true;
@@ -189,7 +240,7 @@ int main(int argc, char* argv[]) {
   auto X = zkFC::load_float_gpu_input(batch_size, input_dim, xin.p);
 
   auto Y_hat = fcnn_inference(X.mont(), fcs, relus, Z_vec, A_vec).unmont();   // demo.cu:119
-  ofstream outfile("demo.out");
+  ofstream outfile(rank == 0 ? string("demo.out") : "demo.rank" + to_string(rank) + ".out");
   outfile << Y_hat << endl;
   outfile.close();
 
@@ -267,6 +318,40 @@ int main(int argc, char* argv[]) {
       return 1;
     }
     challenges = first_challenges;
+  }
+  if (dist) {   // the multi-GPU aggregate: ONE RCCL all-reduce of the ranks' transcript digests (8 x uint64 lanes), no torch
+    uint8_t id[128];
+    const char* idfile = getenv("ZKDL_DIST_ID_FILE");
+    if (rank == 0) {
+      zkdl::check(zk_dist_unique_id(id));
+      if (idfile) {
+        const string tmp = string(idfile) + ".tmp";
+        ofstream f(tmp, ios::binary);
+        f.write(reinterpret_cast<const char*>(id), 128);
+        f.close();
+        rename(tmp.c_str(), idfile);
+      }
+    } else {
+      if (!idfile) throw std::runtime_error("ZKDL_DIST_ID_FILE is not set");
+      for (int tries = 0;; tries++) {
+        ifstream f(idfile, ios::binary);
+        if (f && f.read(reinterpret_cast<char*>(id), 128)) break;
+        if (tries > 3000) throw std::runtime_error("timed out waiting for rank 0's RCCL id");
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));
+      }
+    }
+    zk_dist* d = nullptr;
+    zkdl::check(zk_dist_init(zkdl::ctx(), rank, world, id, &d));
+    uint64_t* lanes_d = zkdl::dalloc<uint64_t>(8);
+    zkdl::check(zk_transcript_digest_dev(zkdl::transcript(), lanes_d));
+    zkdl::check(zk_dist_allreduce_u64(d, lanes_d, 8));
+    uint64_t lanes[8];
+    zkdl::check(zk_memcpy_d2h(zkdl::ctx(), lanes, lanes_d, sizeof lanes));
+    Fr_t agg;
+    zk_dist_lanes_to_fr(lanes, &agg);
+    if (rank == 0) cout << "Aggregate over " << zk_dist_world_size(d) << " ranks (RCCL all-reduce of the transcript digests): " << agg << endl;
+    zk_dist_destroy(d);
+    zk_free(zkdl::ctx(), lanes_d);
   }
   if (do_verify) {  // the verifier's pass: public data + the serialised proof only
     const vector<unsigned char>& buf = first_blob;
