@@ -35,7 +35,10 @@ Rccl* rccl() {
   static bool tried = false;
   if (!tried) {
     tried = true;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+    // ROCm's own librccl (soname librccl.so.1), the one built against the HIP runtime this library is linked with.  A process may carry another
+    // copy (PyTorch wheels bundle a librccl.so bound to their own bundled HIP runtime): its streams and ours are not interchangeable, so it is
+    // deliberately NOT picked up through the global namespace.
+    for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
       r.so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
       if (r.so) break;
     }
