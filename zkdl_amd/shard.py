@@ -66,19 +66,22 @@ class Shard:
         out = []
         tr = Transcript(zk)
         relu_lens_seen = []
-        for kind, i, ch in chal:
+        # the batch-side contractions first (immediate launches: an immediate call settles recorded work, which would cut the ReLU
+        # calls' recorded chains apart), then every ReLU call recorded on one transcript, then ONE read
+        a_dev = {}
+        for c, (kind, i, ch) in enumerate(chal):
+            if kind == "fc":
+                u_bs = ch[0]
+                x_in = wl.A[i - 1] if i > 0 else wl.X
+                a_dev[c] = zk.fr_mul_scalar(zk.fr_partial_me(x_in, u_bs[:kb_l], sh[i]["in_p"]), eq_weight(u_bs[kb_l:], self.rank))   # X~(., u_bs) restricted to this rank's rows
+        for c, (kind, i, ch) in enumerate(chal):
             s = sh[i]
             if kind == "fc":
-                u_bs, u_in, u_out = ch
-                w = eq_weight(u_bs[kb_l:], self.rank)
-                x_in = wl.A[i - 1] if i > 0 else wl.X
-                z_out = wl.Yhat if i == L - 1 else wl.Z[i]
-                a_loc = zk.fr_mul_scalar(zk.fr_partial_me(x_in, u_bs[:kb_l], s["in_p"]), w)       # X~(., u_bs) restricted to this rank's rows
-                out.append(dict(a=a_loc))
+                out.append(dict(a=a_dev[c]))
             else:
                 k_l = kb_l + ceil_log2(s["out_p"])
                 lens = relu_lens(k_l)
-                wl.relus[i].prove(wl.Z[i], wl.A[i], [c[:n] for c, n in zip(ch, lens)], tr)
+                wl.relus[i].prove(wl.Z[i], wl.A[i], [c_[:n] for c_, n in zip(ch, lens)], tr)
                 relu_lens_seen.append(3 * (k_l + 5) + 1 + 32 + 3 * (k_l + 4) + 1 + 16 + 3 * k_l + 2)
                 out.append(dict(fr=None))
         fr, _ = tr.read()
@@ -108,8 +111,8 @@ class Shard:
             return {}
         tr = Transcript(zk)
         keep = []
-        for c in mine:
-            _, i, (u_bs, u_in, u_out) = chal[c]
+        for c in mine:                       # the stand-ins first (immediate launches) ...
+            _, i, _ = chal[c]
             a = None
             for r in range(self.world):
                 ar = zk.upload(gathered[r][c]["a"])
@@ -117,8 +120,10 @@ class Shard:
             z = wl.fcs[i].forward(a)
             if i == L - 1:
                 z = zk.fr_unmont(z)
-            wl.fcs[i].prove(a, z, wl.gens[i], u_bs[:0], u_in, u_out, tr)
             keep.append((a, z))
+        for c, (a, z) in zip(mine, keep):    # ... then every owned layer recorded on one transcript: zipped like an unsharded proof
+            _, i, (u_bs, u_in, u_out) = chal[c]
+            wl.fcs[i].prove(a, z, wl.gens[i], u_bs[:0], u_in, u_out, tr)
         fr, _ = tr.read()
         aff, inf = tr.read_affine()
         tr.close()
@@ -133,8 +138,11 @@ class Shard:
 
     # ---- assembly (after the second all-gather): identical on every rank
     def assemble(self, chal, gathered, owned):
-        """gathered[r][c]: rank r's phase-1 payload of call c; owned[c]: the owner's FC result of call c."""
-        zk, wl, lw, N = self.zk, self.wl, self.lw, self.world
+        """gathered[r][c]: rank r's phase-1 payload of call c; owned[c]: the owner's FC result of call c.
+        A few hundred field operations per ReLU call on values that are already on the host (the gathered payloads): done in Python
+        integers -- through the device they were ~30 tiny launches with a host round trip each per call (two thirds of a sharded
+        proof's wall time at N = 1)."""
+        wl, lw, N = self.wl, self.lw, self.world
         sh = wl.shapes
         kb_l = ceil_log2(wl.B_p)
         frs, affs, infs = [], [], []
@@ -152,27 +160,68 @@ class Shard:
 
             def combine(n_vals, u_top):
                 """sum_rank eq(u_top, rank) * part[off : off + n_vals]"""
-                acc = None
-                for r in range(N):
-                    t = zk.fr_mul_scalar(zk.upload(parts[r][off:off + n_vals]), eq_weight(u_top, r))
-                    acc = t if acc is None else zk.fr_add(acc, t)
-                return acc.download()
+                if N == 1:
+                    return parts[0][off:off + n_vals]
+                ws = [_to_int(eq_weight(u_top, r)) for r in range(N)]
+                return _ints_to_mont([sum(ws[r] * _to_int(parts[r][off + j]) for r in range(N)) % R_MOD for j in range(n_vals)])
 
             for (u, v, kk, nb) in ((ch[0], ch[1], k_l + 5, 32), (ch[2], ch[3], k_l + 4, 16)):
                 pieces.append(combine(3 * kk, u[kk:]))                                   # the low rounds' coefficients
                 off += 3 * kk
-                finals = zk.upload(np.stack([parts[r][off] for r in range(N)]))          # each shard's table folded to one value
+                finals = [_to_int(parts[r][off]) for r in range(N)]                      # each shard's table folded to one value
                 off += 1
-                pieces.append(zk.sumcheck_binary(finals, u[kk:], v[kk:]) if lw else finals.download())   # the log N top rounds + a(0)
+                pieces.append(_ints_to_mont(_top_rounds(finals, None, u[kk:], v[kk:])))  # the log N top rounds + a(0)
                 pieces.append(combine(nb, ch[4][k_l:]))                                  # partial_me(u_rec, nb)
                 off += nb
             pieces.append(combine(3 * k_l, ch[5][k_l:]))                                 # Hadamard: low rounds
             off += 3 * k_l
-            fa = zk.upload(np.stack([parts[r][off] for r in range(N)]))
-            fb = zk.upload(np.stack([parts[r][off + 1] for r in range(N)]))
-            pieces.append(zk.sumcheck_hadamard(fa, fb, ch[5][k_l:], ch[6][k_l:]) if lw else np.concatenate([fa.download(), fb.download()]))
+            fa = [_to_int(parts[r][off]) for r in range(N)]
+            fb = [_to_int(parts[r][off + 1]) for r in range(N)]
+            pieces.append(_ints_to_mont(_top_rounds(fa, fb, ch[5][k_l:], ch[6][k_l:])))
             frs.append(np.concatenate(pieces))
         return np.concatenate(frs), np.concatenate(affs), np.concatenate(infs)
+
+
+def _ints_to_mont(vals):
+    return np.stack([_to_mont(v) for v in vals]) if len(vals) else np.zeros((0, 8), np.uint32)
+
+
+def _top_rounds(a, b, u_top, v_top):
+    """The log N top rounds of an eq-weighted sumcheck over the N values the shards folded to, as field integers: binary
+    (b is None: proof.cu:152-188, sum_g eq(u, g)(a_g^2 - a_g)) or Hadamard (proof.cu:110-137, sum_g eq(u, g) a_g b_g); the weight of
+    pair j in round r is eq(u[r+1:], j); both tables fold with v[r].  Returns the 3 log N coefficients followed by a(0) [, b(0)]."""
+    us = [_to_int(x) for x in np.asarray(u_top).reshape(-1, 8)]
+    vs = [_to_int(x) for x in np.asarray(v_top).reshape(-1, 8)]
+    out = []
+    a = list(a)
+    b = None if b is None else list(b)
+    for r in range(len(us)):
+        half = len(a) // 2
+        w = [1]
+        for ut in us[r + 1:]:
+            w = [x * (1 - ut) % R_MOD for x in w] + [x * ut % R_MOD for x in w]
+        c0 = c1 = c2 = 0
+        for j in range(half):
+            a0, a1 = a[2 * j], a[2 * j + 1]
+            da = a1 - a0
+            if b is None:
+                c0 += w[j] * (a0 * a0 - a0)
+                c1 += w[j] * (2 * a0 * da - da)
+                c2 += w[j] * da * da
+            else:
+                b0, b1 = b[2 * j], b[2 * j + 1]
+                db = b1 - b0
+                c0 += w[j] * a0 * b0
+                c1 += w[j] * (a0 * db + b0 * da)
+                c2 += w[j] * da * db
+        out += [c0 % R_MOD, c1 % R_MOD, c2 % R_MOD]
+        a = [(a[2 * j] + vs[r] * (a[2 * j + 1] - a[2 * j])) % R_MOD for j in range(half)]
+        if b is not None:
+            b = [(b[2 * j] + vs[r] * (b[2 * j + 1] - b[2 * j])) % R_MOD for j in range(half)]
+    out.append(a[0] % R_MOD)
+    if b is not None:
+        out.append(b[0] % R_MOD)
+    return out
 
 
 def prove_sharded(shards, chal, allgather=None):
