@@ -651,13 +651,18 @@ def main():
     latency = None
     if args.latency_reps > 0:
         latency = {}
-        for name, flag in (("msm_rounds", 0), ("derive_rounds", 1)):
+        # a single proof has nothing to share the chip with: its G1 phase goes to the unmasked G1 stream ("g1_mask" = 0), alone ("g1_batch" = 1)
+        zk.set_flag("g1_batch", 1)
+        for name, flag, mask in (("msm_rounds", 0, 0), ("derive_rounds", 1, 0), ("msm_rounds_masked_g1_stream", 0, 1)):
             if flag and not derive:
                 continue
             zk.set_flag("derive_rounds", flag)
-            ts = [run_n(1, 60_000 + 100 * flag + j) for j in range(args.latency_reps + 1)][1:]
+            zk.set_flag("g1_mask", mask)
+            ts = [run_n(1, 60_000 + 100 * flag + 1000 * mask + j) for j in range(args.latency_reps + 1)][1:]
             latency[name] = {"median_ms": float(np.median(ts)), "min_ms": float(min(ts)), "reps": len(ts)}
         zk.set_flag("derive_rounds", 1 if derive else 0)
+        zk.set_flag("g1_mask", 1)
+        zk.set_flag("g1_batch", max(1, args.g1_batch))
         latency["definition"] = "one batch-%d proof, nothing else in flight: host wall time from the first prove call until its G1 phase has finished (demo.cu:124-140)" % batch
     # ---- the two protocol extensions, same pipelined loop (untimed side measurements; --ext-steps 0 skips them):
     #  * sound mode: every sumcheck round challenge from a hash of the rounds before it (zk_fc_prove_fs / zk_relu_prove_fs, csrc/fs_rounds.hip)

@@ -153,6 +153,8 @@ int zk_set_msm_window(zk_ctx* ctx, uint32_t window_bits);   /* 0 = automatic */
  *   "g1_batch"      (default 1) the G1 phases of that many consecutively sealed proofs run as ONE batch (one MSM batch, one derivation,
  *                   one canonicalisation): the latency-bound launches behind the accumulation are shared; a sealed proof then waits for
  *                   its partners (or for anyone touching its transcript, or zk_ctx_sync).  Throughput configuration of bench.py: 2.
+ *   "g1_mask"       (default 1) sealed proofs' G1 phases run on streams confined to every other compute unit, so that the chip-filling accumulation
+ *                   leaves room for the next proofs' Fr chains; 0 = an unmasked stream: what a single proof with nothing in flight wants (latency)
  *   "g1_streams"    (default 0 = all) how many of the context's G1 streams sealed proofs rotate over
  *   "early_g1"      a sealed proof's G1 phase starts behind the openings' scalar preparation (all it needs) instead of behind the whole
  *                   Fr phase; only the digest waits for the rest

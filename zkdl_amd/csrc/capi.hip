@@ -186,6 +186,12 @@ int zk_ctx_create(int device, zk_ctx** out) {
       }
     }
   }
+  if (!ctx->g1_lanes.empty()) {  // the unmasked G1 stream ("g1_mask" = 0: single proofs, nothing to share the chip with)
+    if (hipStreamCreateWithFlags(&ctx->g1_full.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->g1_full.done, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->g1_full.stream = nullptr;
+    }
+  }
   {
     int nt = 0;  // ZKDL_TAIL_STREAMS: streams for the latency-bound tail of a sealed proof's G1 phase (0 = keep it on the G1 stream)
     if (const char* e = getenv("ZKDL_TAIL_STREAMS")) nt = atoi(e);
@@ -238,6 +244,8 @@ int zk_ctx_destroy(zk_ctx* ctx) {
     if (g.stream) (void)hipStreamDestroy(g.stream);
     if (g.done) (void)hipEventDestroy(g.done);
   }
+  if (ctx->g1_full.stream) (void)hipStreamDestroy(ctx->g1_full.stream);
+  if (ctx->g1_full.done) (void)hipEventDestroy(ctx->g1_full.done);
   (void)hipEventDestroy(ctx->fork_ev);
   (void)hipEventDestroy(ctx->pre_ev);
   if (ctx->prof_base) (void)hipEventDestroy(ctx->prof_base);
@@ -605,6 +613,7 @@ int zk_set_flag(zk_ctx* ctx, const char* name, int value) {
   else if (!strcmp(name, "pipeline_fr")) ctx->pipeline_fr = value != 0;
   else if (!strcmp(name, "early_g1")) ctx->early_g1 = value != 0;
   else if (!strcmp(name, "g1_streams")) ctx->g1_active = value < 0 ? 0u : (uint32_t)value;
+  else if (!strcmp(name, "g1_mask")) ctx->g1_masked = value != 0;
   else if (!strcmp(name, "g1_batch")) {
     ZK_TRY(ctx->flush_g1_pending());
     ctx->g1_batch = value < 1 ? 1u : value > 8 ? 8u : (uint32_t)value;

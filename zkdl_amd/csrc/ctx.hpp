@@ -142,6 +142,7 @@ struct zk_ctx {
     for (auto& l : lanes) l.pool.free_lists.clear();
     for (auto& g : g1_lanes) g.pool.free_lists.clear();
     for (auto& g : tail_lanes) g.pool.free_lists.clear();
+    g1_full.pool.free_lists.clear();
   }
 
   // ---- lanes: worker streams for independent per-layer proofs (zk_fc_prove / zk_relu_prove).
@@ -171,6 +172,8 @@ struct zk_ctx {
   bool early_g1 = true;          // sealed proofs: the G1 phase starts behind the opening's scalar preparation, not behind the whole Fr phase
   uint32_t g1_batch = 1;         // sealed proofs whose G1 phases run as ONE batch (1: every proof on its own)
   uint32_t g1_active = 0;        // G1 streams in use, round-robin (0 = all that were created); "g1_streams"
+  Lane g1_full;                  // a G1 stream WITHOUT the CU mask: a proof with nothing to overlap wants the whole chip for its accumulation ("g1_mask" = 0)
+  bool g1_masked = true;
   std::vector<zk_transcript*> g1_pending;  // sealed, Fr phase submitted, G1 phase waiting for partners
   int flush_g1_pending();        // layers.hip
   uint32_t layer_serial = 0;  // next zk_fc / zk_relu serial number (their lane hint)
@@ -190,12 +193,14 @@ struct zk_ctx {
       if (g.dirty) (void)hipStreamWaitEvent(st, g.done, 0);
     for (auto& g : tail_lanes)
       if (g.dirty) (void)hipStreamWaitEvent(st, g.done, 0);
+    if (g1_full.dirty) (void)hipStreamWaitEvent(st, g1_full.done, 0);
   }
   void join_all() {
     join_lanes();
     wait_g1(main_stream);
     for (auto& g : g1_lanes) g.dirty = false;
     for (auto& g : tail_lanes) g.dirty = false;
+    g1_full.dirty = false;
   }
 
   int fail(int code, const std::string& msg) {

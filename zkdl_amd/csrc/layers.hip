@@ -373,7 +373,7 @@ int zk_transcript::seal_pair(zk_transcript* other, uint64_t* out8_d, uint64_t* o
 static int g1_phase_run(zk_ctx* ctx, const std::vector<zk_transcript*>& trs) {
   if (trs.empty()) return ZK_OK;
   const size_t n_g1s = ctx->g1_active && ctx->g1_active < ctx->g1_lanes.size() ? ctx->g1_active : ctx->g1_lanes.size();
-  zk_ctx::Lane& g = ctx->g1_lanes[ctx->next_g1++ % n_g1s];
+  zk_ctx::Lane& g = (!ctx->g1_masked && ctx->g1_full.stream) ? ctx->g1_full : ctx->g1_lanes[ctx->next_g1++ % n_g1s];
   for (zk_transcript* t : trs) {
     t->sealed_stream = g.stream;
     if (!t->sealed_ev && hipEventCreateWithFlags(&t->sealed_ev, hipEventDisableTiming) != hipSuccess) return ctx->fail(ZK_ERR_DEVICE, "hipEventCreate failed");
