@@ -186,8 +186,20 @@ int zk_ctx_create(int device, zk_ctx** out) {
       }
     }
   }
-  if (!ctx->g1_lanes.empty()) {  // the unmasked G1 stream ("g1_mask" = 0: single proofs, nothing to share the chip with)
-    if (hipStreamCreateWithFlags(&ctx->g1_full.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->g1_full.done, hipEventDisableTiming) != hipSuccess) {
+  if (!ctx->g1_lanes.empty()) {  // the G1 stream over ALL compute units ("g1_mask" = 0: single proofs, nothing to share the chip with).  Created through the
+    // CU-mask call with a full mask: such a stream gets a hardware queue of its own -- an ordinary stream shares one with the Fr lanes, and a proof's
+    // G1 phase then measured 6.3 ms instead of 5.1 ms on the half-chip stream
+    hipDeviceProp_t prop;
+    bool ok = false;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+      std::vector<uint32_t> full((size_t)(prop.multiProcessorCount + 31) / 32, 0xffffffffu);
+      ok = hipExtStreamCreateWithCUMask(&ctx->g1_full.stream, (uint32_t)full.size(), full.data()) == hipSuccess;
+    }
+    if (!ok) {
+      (void)hipGetLastError();
+      ok = hipStreamCreateWithFlags(&ctx->g1_full.stream, hipStreamNonBlocking) == hipSuccess;
+    }
+    if (!ok || hipEventCreateWithFlags(&ctx->g1_full.done, hipEventDisableTiming) != hipSuccess) {
       (void)hipGetLastError();
       ctx->g1_full.stream = nullptr;
     }
