@@ -56,7 +56,7 @@ class Workload:
     layers, quantised input, inference (Z_i, A_i, aux bits).  Synthetic weights in model.py's init
     distribution, synthetic N(0,1) inputs; seeded per rank so ranks prove independent batches."""
 
-    def __init__(self, zk, dims, batch, seed, inflight=2, rows=None):
+    def __init__(self, zk, dims, batch, seed, inflight=2, rows=None, full_tables=0):
         """rows = (lo, hi): keep only that slice of the batch (one rank's shard of ONE proof, zkdl_amd/shard.py): the
         weights, generators and the full input are the same as without it."""
         from oracle_free_gen import generator_jac
@@ -72,7 +72,8 @@ class Workload:
         zk.seed(0xC0FFEE + seed)
         L = len(self.shapes)
         self.gens, self.fcs, self.info = [], [], {}
-        t_gen = t_commit = 0.0
+        t_gen = t_commit = t_full = 0.0
+        full_bytes = 0
         pairs = 0
         for s in self.shapes:
             # generators = G * random scalars (demo.cu:81-82)
@@ -82,6 +83,12 @@ class Workload:
             zk.sync()
             t_gen += time.perf_counter() - t0
             self.gens.append(g)
+            if full_tables:                      # every signed digit of every window of this layer's generators: the openings' MSMs then need no buckets
+                t0 = time.perf_counter()
+                g.prepare_full(full_tables)
+                zk.sync()
+                t_full += time.perf_counter() - t0
+                full_bytes += 96 * s["n_gens"] * ((254 + 2 + full_tables - 1) // full_tables) * (1 << (full_tables - 1))
             w = rng.uniform(-1.0 / np.sqrt(s["n_in"]), 1.0 / np.sqrt(s["n_in"]), size=(s["n_in"], s["n_out"])).astype(np.float32)
             wd = zk.upload_f32(w)
             zk.sync()
@@ -111,7 +118,8 @@ class Workload:
         # only after its own G1 phase has finished, so with T transcripts the period is >= (Fr + G1 chain) / T
         self.trs = [Transcript(zk) for _ in range(max(2, inflight))]
         self.tr = self.trs[0]
-        self.info = dict(setup_generators_s=t_gen, setup_commit_s=t_commit, commit_pairs=pairs,
+        self.full_tables = full_tables
+        self.info = dict(setup_generators_s=t_gen, setup_commit_s=t_commit, setup_full_tables_s=t_full, full_table_bytes=full_bytes, commit_pairs=pairs,
                          commit_mops=pairs / t_commit / 1e6, inference_s=t_fwd)
         # algorithmic Fr bytes of one proof: sumcheck 96*S (binary) / 192*S (ip, hadamard),
         # me 32*n, partial_me 32*n*(1+2^-k)
@@ -273,13 +281,15 @@ def cpu_baseline_check_only(zk, wl, calls, parity):
     return cpu_baseline(zk, wl, "sample", parity, calls=calls)
 
 
-def msm_fullwidth_probe(zk, log_pairs=24):
+def msm_fullwidth_probe(zk, log_pairs=24, full_tables=0):
     """G1 MSM Mop/s (BASELINE.json metric, second half): q independent MSMs over 2048 generators with FULL-WIDTH
     (255-bit, uniform) scalars, q * 2048 = 2^log_pairs (point, scalar) pairs, through zk_msm_batch; HIP-event timed."""
     from oracle_free_gen import generator_jac
     n = 2048
     q = (1 << log_pairs) // n
     g = zk.gens(zk.g1_mul(zk.g1_fill(n, generator_jac()), zk.fr_random(n)))
+    if full_tables:
+        g.prepare_full(full_tables)
     sc = zk.fr_random(n * q)
     out = zk.msm_batch(g, sc.view(0, n * min(q, 64)))           # builds the window tables, warms the pools
     zk.sync()
@@ -288,7 +298,8 @@ def msm_fullwidth_probe(zk, log_pairs=24):
     ms = zk.timer_stop_ms()
     del out, sc
     g.close()
-    return {"pairs": n * q, "n_gens": n, "msms": q, "ms": ms, "mops": n * q / ms / 1e3, "scalars": "uniform 255-bit"}
+    return {"pairs": n * q, "n_gens": n, "msms": q, "ms": ms, "mops": n * q / ms / 1e3, "scalars": "uniform 255-bit",
+            "method": ("precomputed digit tables, window %d bits (no buckets)" % full_tables) if full_tables else "bucket method (Pippenger), 10-bit windows"}
 
 
 def spawn_ranks(n, argv):
@@ -407,6 +418,8 @@ def main():
                     "they have no later proofs to hide the longer derived form under")
     ap.add_argument("--pair", type=int, default=1, choices=[1, 2], help="proofs submitted together (zk_transcript_seal_pair): 2 = the Fr phases of two consecutive "
                     "proofs share their launches; every proof is still its own batch-256 proof with its own transcript and digest row")
+    ap.add_argument("--full-tables", type=int, default=12, help="window width of the precomputed digit tables of every layer's generators (zk_gens_prepare_full: "
+                    "96 B x n_gens x windows x 2^(c-1): 62 GB for the 18M MLP at c = 12); the openings' MSMs then run without buckets; 0 = the bucket method only")
     ap.add_argument("--g1-streams", type=int, default=-1, help="G1 streams sealed proofs rotate over (-1: one when --g1-batch > 1, else the library's two)")
     ap.add_argument("--g1-batch", type=int, default=2, help="sealed proofs whose G1 phases (MSM batch, derived round commitments, canonical form) run as ONE batch: "
                     "the latency-bound launches behind the accumulation are shared (zk_set_flag g1_batch); a proof then waits for its partners")
@@ -510,7 +523,8 @@ def main():
     dims, batch = WORKLOADS[args.workload]
     if args.mode == "shard":
         return run_sharded(args, zk, dims, batch, rank, world, dist)
-    wl = Workload(zk, dims, batch, seed=rank, inflight=args.inflight)
+    ft = args.full_tables if (args.msm == "pippenger" and not args.msm_window and args.workload.startswith(("mlp18m", "tiny"))) else 0
+    wl = Workload(zk, dims, batch, seed=rank, inflight=args.inflight, full_tables=ft)
 
     # The G1 phase of every proof (MSM batch, canonicalisation, digest) is ordered on the library's G1 stream; the Fr
     # phase of the next proof runs beside it on the worker lanes.  Every proof leaves its digest (8 x uint64 lanes)
@@ -774,12 +788,23 @@ def main():
     klo = [ceil_log2(s_["n_gens"]) for s_ in wl.shapes]
     real_pairs = sum(((k_ + 1) if derive else (2 * k_ + 1)) * s_["n_gens"] + s_["m"] for k_, s_ in zip(klo, wl.shapes))
     g1_model = None
+    ft_on = bool(getattr(wl, "full_tables", 0)) and "msm_table_accum" in prof
+    if ft_on:
+        # the openings' MSMs on precomputed digit tables: (real_pairs - the com(u_hi) MSMs over the commitment points) x windows mixed additions, then one
+        # addition per lane partial; only the 8 com(u_hi) MSMs (m points each) are left on the bucket path below
+        W_ft = (254 + 2 + wl.full_tables - 1) // wl.full_tables
+        ft_pairs = real_pairs - sum(s_["m"] for s_ in wl.shapes)
+        macs_per_step["msm_table_accum"] = ft_pairs * W_ft * 10 * FP_MACS
+        macs_per_step["msm_table_sum"] = ft_pairs * W_ft / 16.0 * 14 * FP_MACS
+        fam["msm_table_accum"] = (["k_msmf_accum"], 100, None)
+        fam["msm_table_sum"] = (["k_msmf_reduce"], None, None)
     if "msm_accum" in prof and args.msm == "pippenger":
         c_win, W_win, chunk = (args.msm_window or 10), None, 16
         W_win = (254 + 2 + c_win - 1) // c_win
         slots = prof["msm_accum"]["bytes"] / 100.0 / nprof
-        items = min(slots, real_pairs * float(W_win))
-        n_jobs = sum((2 * k_ + 2) if derive else (3 * k_ + 2) for k_ in klo)          # MSMs of one proof (derived: T0_r, T1_r, final generator, com(u_hi))
+        bucket_pairs = sum(s_["m"] for s_ in wl.shapes) if ft_on else real_pairs
+        items = min(slots, bucket_pairs * float(W_win))
+        n_jobs = len(klo) if ft_on else sum((2 * k_ + 2) if derive else (3 * k_ + 2) for k_ in klo)   # MSMs on the bucket path (derived: T0_r, T1_r, final generator, com(u_hi))
         B = 1 << (c_win - 1)
         LB = c_win // 2
         nlo, nhi = 1 << LB, (B >> LB) + 1
@@ -787,7 +812,8 @@ def main():
         JADD, JDBL, INV = 16, 7, 485                                                  # Jacobian 11M+5S, 2M+5S (g1q.hpp); Fermat inverse with 4-bit windows
         n_derived = sum(k_ * k_ for k_ in klo) if derive else 0                       # coef * point products behind the batch (T_0 .. T_{k-1}: 2r + 1 each)
         n_g1_out = sum(3 * k_ + 2 for k_ in klo)                                      # transcript points put into canonical form
-        g1_model = {"items": items, "jobs": n_jobs, "derived_products": n_derived, "points_canonicalised": n_g1_out, "window_bits": c_win, "windows": W_win}
+        g1_model = {"bucket_items": items, "bucket_jobs": n_jobs, "derived_products": n_derived, "points_canonicalised": n_g1_out, "window_bits": c_win, "windows": W_win,
+                    "table_items": (ft_pairs * W_ft if ft_on else 0), "table_window_bits": (wl.full_tables if ft_on else None)}
         macs_per_step["msm_accum"] = items * MADD * FP_MACS
         # stitching: a bucket that spans chunks t0..t1 costs t1 - t0 additions: in total one per chunk boundary that falls inside a bucket (~ all of them)
         macs_per_step["msm_combine"] = max(items / chunk - n_jobs, 0.0) * ADD * FP_MACS
@@ -838,7 +864,7 @@ def main():
         dom = max(modelled, key=lambda k: kernels[k]["ms_per_step"])
         roofline = dict(roofline_of(dom))
         # chip-filling: launches of at least ~4 waves per SIMD's worth of workgroups; on this path that is the accumulation and the big rounds
-        filling = [k for k in modelled if k in ("msm_accum", "sumcheck_bin_round", "sumcheck_hp_round", "binp_words", "fr_contract")]
+        filling = [k for k in modelled if k in ("msm_table_accum", "msm_accum", "sumcheck_bin_round", "sumcheck_hp_round", "binp_words", "fr_contract")]
         fill = max(filling, key=lambda k: kernels[k]["ms_per_step"]) if filling else dom
         roofline["measured"] = "standalone launches (worker streams off) after the timed region, HIP events on the launching stream; rocprofv3 of `bench.py --serial` agrees (profiles/)"
         roofline["selection"] = "the family with the most device time per proof among all families with a MAC model (roofline_all); roofline_chip_filling = the longest family whose launches fill the chip"
@@ -857,7 +883,7 @@ def main():
            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (Fr) / u32x12 (Fp) limbs",
            "data": "synthetic",
            "config": {"workload": args.workload, "dims": dims, "batch_per_gpu": batch, "parallelism": "independent proofs per rank, one RCCL all-reduce of the run aggregate",
-                      "msm": args.msm, "derive_rounds": bool(derive), "inflight": args.inflight, "g1_batch": args.g1_batch, "g1_streams": (g1_streams or 2), "proofs_per_submission": 2 if paired else 1, "prewarm_process": not args.no_prewarm,
+                      "msm": args.msm, "derive_rounds": bool(derive), "inflight": args.inflight, "g1_batch": args.g1_batch, "g1_streams": (g1_streams or 2), "full_table_window_bits": ft, "proofs_per_submission": 2 if paired else 1, "prewarm_process": not args.no_prewarm,
                       "drain_form_proofs": (min(args.drain, args.steps) if derive else 0), "spinup_ms": args.spinup_ms, "spinup_proofs": n_spin,
                       "warmup_drain_form_proofs": (min(2, args.warmup) if derive and args.warmup >= 2 else 0),
                       "schedule_note": "the last drain_form_proofs proofs of the timed region run every round commitment as an MSM (derive_rounds off): they have no later proof to hide the derivation under"},
@@ -869,10 +895,12 @@ def main():
            "roofline_chip_filling": roofline_fill, "roofline_all": roofline_all, "g1_model": g1_model, "kernels": kernels,
            "g1_msm_mops_commit": wl.info["commit_mops"]}
     if "msm_accum" in prof:
-        g1_ms = sum(prof[k]["ms"] for k in prof if k.startswith("msm_") or k == "g1_canonicalise") / nprof
+        g1_ms = sum(prof[k]["ms"] for k in prof if (k.startswith("msm_") and k != "msm_fulltable_build") or k == "g1_canonicalise") / nprof
         out["g1_msm_mops_prove"] = real_pairs / g1_ms / 1e3 if g1_ms > 0 else None   # nonzero full-width (point, scalar) pairs of one proof / its G1 kernels' time
     if rank == 0 and not args.no_msm_probe and args.workload.startswith("mlp18m"):
-        out["g1_msm_fullwidth"] = msm_fullwidth_probe(zk)
+        out["g1_msm_fullwidth"] = msm_fullwidth_probe(zk, full_tables=wl.full_tables)
+        if wl.full_tables:
+            out["g1_msm_fullwidth_bucket_method"] = msm_fullwidth_probe(zk, full_tables=0)
         out["g1_msm_mops"] = out["g1_msm_fullwidth"]["mops"]
     if world > 1:
         dist.barrier()

@@ -35,7 +35,7 @@ zk_relu_destroy zk_relu_forward zk_relu_sign zk_relu_mag_bin zk_relu_rem_bin zk_
 zk_transcript_destroy zk_transcript_reset zk_transcript_flush zk_transcript_counts zk_transcript_read zk_transcript_read_affine
 zk_transcript_digest zk_transcript_digest_dev zk_transcript_serialize zk_transcript_seal zk_transcript_seal_pair zk_transcript_stream
 zk_verify_fc zk_verify_relu zk_verify_open zk_fs_derive zk_sha256 zk_fc_prove_fs zk_relu_prove_fs zk_fs_round_challenges zk_relu_set_activation zk_leaky_prove zk_verify_leaky zk_act_open zk_verify_act_open zk_dist_unique_id zk_dist_init zk_dist_world_size zk_dist_sum_rows zk_dist_allreduce_u64
-zk_dist_lanes_to_fr zk_dist_destroy""".split()
+zk_dist_lanes_to_fr zk_dist_destroy zk_gens_prepare_full""".split()
 
 
 class ZkError(RuntimeError):
@@ -588,6 +588,10 @@ class Gens:
 
     def points(self):
         return DevArray(self.zk, self.n, 36, ptr=self.zk.lib.zk_gens_points(self.h), own=False)
+
+    def prepare_full(self, window_bits=12):
+        """Precompute every signed digit of every window (zk_gens_prepare_full): full-width MSMs over these generators then run without buckets."""
+        self.zk._chk(self.zk.lib.zk_gens_prepare_full(self.zk.ctx, self.h, _u32(window_bits)))
 
     def close(self):
         if self.h:

@@ -624,6 +624,7 @@ int zk_set_flag(zk_ctx* ctx, const char* name, int value) {
   else if (!strcmp(name, "derive_rounds")) ctx->derive_rounds = value != 0;
   else if (!strcmp(name, "pipeline_fr")) ctx->pipeline_fr = value != 0;
   else if (!strcmp(name, "early_g1")) ctx->early_g1 = value != 0;
+  else if (!strcmp(name, "full_tables")) ctx->full_tables = value != 0;
   else if (!strcmp(name, "g1_streams")) ctx->g1_active = value < 0 ? 0u : (uint32_t)value;
   else if (!strcmp(name, "g1_mask")) ctx->g1_masked = value != 0;
   else if (!strcmp(name, "g1_batch")) {
@@ -646,6 +647,11 @@ int zk_gens_create(zk_ctx* ctx, const zk_g1j* gens, uint32_t n, zk_gens** out) {
   CHECK_CTX(ctx);
   CHECK_PTR(ctx, gens); CHECK_HOST(ctx, out);
   return gens_create(ctx, J(gens), n, true, out);
+}
+int zk_gens_prepare_full(zk_ctx* ctx, zk_gens* g, uint32_t window_bits) {
+  CHECK_CTX(ctx);
+  if (!g) return ctx->fail(ZK_ERR_ARG, "null zk_gens");
+  return gens_prepare_full(ctx, g, window_bits);
 }
 int zk_gens_destroy(zk_gens* g) {
   if (!g) return ZK_ERR_ARG;

@@ -37,6 +37,7 @@ void gens_destroy(zk_gens* g) {
     dev_free(g->ctx, kv.second.pts);
     dev_free(g->ctx, kv.second.inf);
   }
+  dev_free(g->ctx, g->full.pts);
   dev_free(g->ctx, g->pts);
   delete g;
 }

@@ -48,6 +48,7 @@ struct zk_ctx {
   bool pipeline_fr = true;     // sealed proofs: do not join the Fr groups on the main stream (next proof's groups run right behind)
   bool derive_rounds = false;  // me_open: T_1 .. T_{k-1} from the folding relation behind the MSM batch instead of as MSMs (msm.hip);
                                // off by default: -31 % msm_accum but a 13 ms scalar-multiplication tail, 2 % net
+  bool full_tables = true;  // full-width MSM jobs over generator sets that were prepared with zk_gens_prepare_full take the bucket-free path
   bool relu_bytes = true;   // ... through byte histograms (rounds 0-4 / 0-3 without a table) rather than the three-round table form
   // timing
   hipEvent_t t0 = nullptr, t1 = nullptr;

@@ -11,11 +11,18 @@ struct G1Table {  // affine window table: pts[w*n + j] = 2^(c*w) * base_j ; inf[
 }  // namespace zk
 
 namespace zk {
+struct G1FullTable {  // every signed digit of every window precomputed: pts[((j * W + w) << (c - 1)) + (d - 1)] = d * 2^(c w) * base_j, d = 1 .. 2^(c-1)
+  uint32_t n = 0, c = 0, W = 0;
+  G1A* pts = nullptr;       // affine, the bucket pipeline's Montgomery domain (fq28.hpp); 96 B x n x W x 2^(c-1)
+  const uint8_t* inf = nullptr;  // [n] base-at-infinity flags (the window table's)
+};
 struct MsmJobHost {  // one pending MSM: *out = sum_j mags[j] * base_j over table T (W windows in use)
   const G1Table* T;
   const Fr* mags;
   G1J* out;
   uint32_t W;
+  const G1FullTable* F = nullptr;  // not null: the job runs on the bucket-free path (msm.hip: k_msmf_*)
+  uint8_t pat_r = 0xff, pat_par = 0;  // scalars known to vanish outside { i : ((i >> pat_r) & 1) == pat_par } (0xff: dense) -- T0_r / T1_r of the flattened opening
 };
 struct DeriveJobHost {  // T_1 .. T_{k-1} of one me_open, derived from T_0 and the T0_j / T1_j behind the MSM batch (msm.hip)
   G1J* proof;            // the me_open's 3k+1 transcript slots
@@ -36,6 +43,7 @@ struct zk_gens {  // Commitment (commitment.cuh:8-23): generator tensor + lazily
   uint32_t n = 0;
   zk::G1J* pts = nullptr;
   std::map<uint32_t, zk::G1Table> tables;  // keyed by window width c
+  zk::G1FullTable full;                    // optional (zk_gens_prepare_full): all digit multiples, for full-width scalars
 };
 
 struct zk_fc {  // zkFC, zkfc.cuh:16-33: padded weights (Montgomery, [in][out]) + their commitment
@@ -108,7 +116,10 @@ int gens_create(zk_ctx* ctx, const G1J* gens_d, uint32_t n, bool copy, zk_gens**
 void gens_destroy(zk_gens* g);
 int gens_table(zk_ctx* ctx, zk_gens* g, uint32_t c, uint32_t W, const G1Table** out);
 int msm_batch_dev(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_unmont, bool probe_bits, G1J* out);
-int msm_enqueue(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_unmont, bool probe_bits, G1J* out, MsmQueue* queue, const uint32_t* out_idx = nullptr);
+// pattern (optional, q entries): (r << 1) | parity per row, 0x1fe = dense -- see MsmJobHost::pat_r
+int msm_enqueue(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_unmont, bool probe_bits, G1J* out, MsmQueue* queue, const uint32_t* out_idx = nullptr,
+                const uint16_t* pattern = nullptr);
+int gens_prepare_full(zk_ctx* ctx, zk_gens* g, uint32_t c);
 int msm_run_derives(zk_ctx* ctx, const std::vector<DeriveJobHost>& derives);
 int msm_flush(zk_ctx* ctx, MsmQueue* queue);
 int msm_run_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs, uint32_t c);

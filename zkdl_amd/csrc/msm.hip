@@ -592,8 +592,216 @@ uint32_t msm_num_windows(uint32_t bits, uint32_t c) {
   return W ? W : 1;
 }
 
+// ------------------------------------------------------------------ the bucket-free path: full digit tables
+// The generators of a layer never change, and 288 GB of HBM hold a lot of table: with EVERY signed digit of every window precomputed
+// (d * 2^(c w) * G_j for d = 1 .. 2^(c-1): at c = 12, 22 windows x 2048 entries x 96 B = 4.3 MB per generator, 8.9 GB per 2048-generator
+// layer) an MSM is nothing but mixed additions of table entries: no buckets, so no sort, no stitching of chunk partials, no row / column /
+// weighted bucket reduction -- and 22 windows instead of 26.  Per proof of the 18M-parameter MLP: 4.3 M mixed additions + 0.27 M additions of
+// lane partials, against 5.1 M + ~0.7 M additions in three latency-bound reduction launches on the bucket path.  The table reads are random
+// 96-byte accesses into gigabytes: ~0.6 GB of HBM traffic per proof, which the accumulation's arithmetic hides.
+//   k_fulltable_build  one lane per (generator, window) row: 2^(c-1) - 1 chained mixed additions, put into affine form 64 at a time with one
+//                      shared inversion (Montgomery's trick); setup, ~0.1 s per layer
+//   k_msmf_accum       each lane adds MSM_CHUNK consecutive (point, window) items of one job (point-major: a lane recodes a scalar once)
+//   k_msmf_reduce      one workgroup per job sums the lanes' partials (a few chained additions per lane, then a shuffle / LDS tree)
+struct FullJob {
+  const G1A* tab;
+  const uint8_t* inf;
+  const Fr* mags;
+  G1J* out;
+  uint32_t n, W, nnz;
+  uint32_t pat_r, pat_par;
+  uint64_t part_off;
+};
+static constexpr uint32_t FT_SEG = 64;  // points put into affine form per shared inversion
+__global__ void __launch_bounds__(64) k_fulltable_build(const G1A* __restrict__ win, const uint8_t* __restrict__ inf, uint32_t n, uint32_t W, uint32_t half,
+                                                         G1A* __restrict__ out, G1X* __restrict__ scratch, Fq* __restrict__ prefix) {
+  __shared__ Fq wtab[16 * 64];
+  const uint32_t row = blockIdx.x * 64u + threadIdx.x;  // row = j * W + w
+  if (row >= n * W) return;
+  const uint32_t j = row / W, w = row % W;
+  if (inf[(size_t)w * n + j]) return;  // an infinite base: its entries are never read
+  const G1A B = win[(size_t)w * n + j];
+  const Fq bx = fq_unpack(B.x), by = fq_unpack(B.y);
+  G1X* sc = scratch + (size_t)row * FT_SEG;
+  Fq* pr = prefix + (size_t)row * FT_SEG;
+  G1A* dst = out + (size_t)row * half;
+  G1X acc = g1x_zero();
+  for (uint32_t d0 = 0; d0 < half; d0 += FT_SEG) {
+    const uint32_t cnt = half - d0 < FT_SEG ? half - d0 : FT_SEG;
+    Fq run = fq_one();
+#pragma unroll 1
+    for (uint32_t i = 0; i < cnt; i++) {
+      acc = g1x_madd(acc, bx, by);  // (d0 + i + 1) * B
+      sc[i] = acc;
+      run = fq_mul(run, fq_mul(acc.zz, acc.zzz));
+      pr[i] = run;
+    }
+    Fq inv = fq_inv(fq_norm(run), wtab + threadIdx.x, 64);
+#pragma unroll 1
+    for (uint32_t ii = cnt; ii > 0; ii--) {
+      const uint32_t i = ii - 1;
+      const G1X p = sc[i];
+      const Fq it = i ? fq_mul(inv, pr[i - 1]) : inv;  // 1 / (zz zzz) of point i
+      inv = fq_mul(inv, fq_mul(p.zz, p.zzz));
+      const Fq x = fq_mul(p.x, fq_mul(it, p.zzz));      // X / ZZ
+      const Fq y = fq_mul(p.y, fq_mul(it, p.zz));       // Y / ZZZ
+      // canonical, in the pipeline's domain: out of it (x 2^384, fully reduced) and back in by eight modular doublings (as k_table_nform)
+      Fp cx = fq_to_fp(x), cy = fq_to_fp(y);
+#pragma unroll 1
+      for (int t = 0; t < 8; t++) {
+        cx = fp_dbl(cx);
+        cy = fp_dbl(cy);
+      }
+      G1A o;
+      o.x = cx;
+      o.y = cy;
+      dst[d0 + i] = o;
+    }
+  }
+}
+
+// i-th index of { x : ((x >> r) & 1) == par }
+__device__ __forceinline__ uint32_t pat_index(uint32_t t, uint32_t r, uint32_t par) {
+  if (r >= 32u) return t;
+  return ((t >> r) << (r + 1)) | (par << r) | (t & ((1u << r) - 1u));
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZK_ACCUM_WAVES, ZK_ACCUM_WAVES))) k_msmf_accum(const FullJob* __restrict__ jobs, uint32_t c, RecodeK K,
+                                                                                                                    G1X* __restrict__ partial) {
+  const FullJob job = jobs[blockIdx.y];
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t items = (uint64_t)job.nnz * job.W;
+  const uint64_t e0 = (uint64_t)t * MSM_CHUNK;
+  if (e0 >= items) return;
+  const uint64_t e1 = e0 + MSM_CHUNK < items ? e0 + MSM_CHUNK : items;
+  uint32_t pt = (uint32_t)(e0 / job.W), w = (uint32_t)(e0 - (uint64_t)pt * job.W);
+  const uint32_t half_log = c - 1;
+  G1X acc = g1x_zero();
+  Recoded rc;
+  uint32_t i = 0;
+  bool live = false, fresh = true;
+  for (uint64_t e = e0; e < e1; e++) {
+    if (fresh) {
+      i = pat_index(pt, job.pat_r, job.pat_par);
+      live = !job.inf[i];
+      if (live) rc = recode_prepare(job.mags[i], K);
+      fresh = false;
+    }
+    if (live) {
+      bool neg;
+      const uint32_t d = recode_digit(rc, c, w, neg);
+      if (d) {
+        G1A P = job.tab[((((size_t)i * job.W + w)) << half_log) + (d - 1)];
+        if (neg) P.y = fp_neg(P.y);
+        acc = g1x_madd<ACCUM_INLINE>(acc, fq_unpack(P.x), fq_unpack(P.y));
+      }
+    }
+    if (++w == job.W) {
+      w = 0;
+      pt++;
+      fresh = true;
+    }
+  }
+  partial[job.part_off + t] = acc;
+}
+__global__ void __launch_bounds__(256) k_msmf_reduce(const FullJob* __restrict__ jobs, const G1X* __restrict__ partial) {
+  __shared__ G1X sm[4];
+  const FullJob job = jobs[blockIdx.x];
+  const uint64_t items = (uint64_t)job.nnz * job.W;
+  const uint32_t np = (uint32_t)((items + MSM_CHUNK - 1) / MSM_CHUNK);
+  G1X acc = g1x_zero();
+  for (uint32_t p = threadIdx.x; p < np; p += 256) acc = g1x_add(acc, partial[job.part_off + p]);
+#pragma unroll 1
+  for (int m = 1; m < 64; m <<= 1) acc = g1x_add(acc, g1x_shfl_xor(acc, m));
+  if ((threadIdx.x & 63u) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    acc = g1x_add(g1x_add(sm[0], sm[1]), g1x_add(sm[2], sm[3]));
+    *job.out = g1x_to_jacobian(acc);
+  }
+}
+
+int gens_prepare_full(zk_ctx* ctx, zk_gens* g, uint32_t c) {
+  if (c < 4 || c > 14) return ctx->fail(ZK_ERR_ARG, "zk_gens_prepare_full: window width 4 .. 14");
+  if (g->full.pts && g->full.c == c) return ZK_OK;
+  if (g->full.pts) {
+    ctx->wait_g1(ctx->stream);
+    dev_free(ctx, g->full.pts);
+    g->full = G1FullTable();
+  }
+  const uint32_t W = msm_num_windows(254, c), half = 1u << (c - 1);
+  const G1Table* T = nullptr;
+  ZK_TRY(gens_table(ctx, g, c, W, &T));
+  const size_t rows = (size_t)g->n * W, total = rows * half;
+  G1FullTable F;
+  F.n = g->n;
+  F.c = c;
+  F.W = W;
+  F.inf = T->inf;
+  if (dev_alloc(ctx, (void**)&F.pts, total * sizeof(G1A)) != hipSuccess) return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: full digit table");
+  {
+    ZK_ALLOC(ctx, scratch, G1X, rows * FT_SEG);
+    ZK_ALLOC(ctx, prefix, Fq, rows * FT_SEG);
+    ZK_LAUNCH(ctx, "msm_fulltable_build", (uint64_t)sizeof(G1A) * total, k_fulltable_build, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, (const G1A*)T->pts, (const uint8_t*)T->inf,
+              g->n, W, half, F.pts, scratch.get(), prefix.get());
+  }
+  g->full = F;
+  return ZK_OK;
+}
+
+static int msm_run_full_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs) {
+  const uint32_t nj = (uint32_t)hjobs.size();
+  if (nj == 0) return ZK_OK;
+  if (nj > 65535) return ctx->fail(ZK_ERR_ARG, "MSM: more than 65535 jobs in one batch");
+  std::vector<FullJob> jobs(nj);
+  uint64_t parts = 0, items_all = 0;
+  uint32_t max_lanes = 0;
+  const uint32_t c = hjobs[0].F->c, W = hjobs[0].F->W;
+  for (uint32_t i = 0; i < nj; i++) {
+    const MsmJobHost& h = hjobs[i];
+    if (h.F->c != c || h.F->W != W) return ctx->fail(ZK_ERR_ARG, "MSM: full tables of different window widths in one batch");
+    FullJob& j = jobs[i];
+    j.tab = h.F->pts;
+    j.inf = h.F->inf;
+    j.mags = h.mags;
+    j.out = h.out;
+    j.n = h.F->n;
+    j.W = W;
+    j.pat_r = h.pat_r == 0xff ? 32u : h.pat_r;
+    j.pat_par = h.pat_par;
+    j.nnz = h.pat_r == 0xff ? j.n : j.n / 2;
+    j.part_off = parts;
+    const uint64_t items = (uint64_t)j.nnz * W;
+    const uint32_t lanes = (uint32_t)((items + MSM_CHUNK - 1) / MSM_CHUNK);
+    parts += lanes;
+    items_all += items;
+    max_lanes = lanes > max_lanes ? lanes : max_lanes;
+  }
+  RecodeK K = make_recode_k(c, W);
+  ZK_ALLOC(ctx, djobs, FullJob, nj);
+  {
+    const size_t bytes = (size_t)nj * sizeof(FullJob);
+    void* st = bytes <= (1u << 20) ? ctx->stage_put(jobs.data(), bytes) : nullptr;
+    if (st) ZK_TRY(dev_copy(ctx, djobs.get(), st, (bytes + 15) & ~(size_t)15));
+    else ZK_TRY(host_to_dev(ctx, djobs.get(), jobs.data(), bytes));
+  }
+  ZK_ALLOC(ctx, partial, G1X, parts);
+  ZK_LAUNCH(ctx, "msm_table_accum", 100ull * items_all, k_msmf_accum, dim3((max_lanes + 63) / 64, nj), dim3(64), 0, (const FullJob*)djobs.get(), c, K, partial.get());
+  ZK_LAUNCH(ctx, "msm_table_sum", (uint64_t)sizeof(G1X) * parts, k_msmf_reduce, dim3(nj), dim3(256), 0, (const FullJob*)djobs.get(), (const G1X*)partial.get());
+  return ZK_OK;
+}
+
 // run a list of MSM jobs that share the window width c (their tables were built with it)
-int msm_run_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs, uint32_t c) {
+static int msm_run_bucket_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs, uint32_t c);
+int msm_run_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& all, uint32_t c) {
+  bool any_full = false;
+  for (const auto& h : all) any_full = any_full || h.F != nullptr;
+  if (!any_full) return msm_run_bucket_jobs(ctx, all, c);
+  std::vector<MsmJobHost> full, bucket;
+  for (const auto& h : all) (h.F ? full : bucket).push_back(h);
+  ZK_TRY(msm_run_full_jobs(ctx, full));
+  return msm_run_bucket_jobs(ctx, bucket, c);
+}
+static int msm_run_bucket_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs, uint32_t c) {
   const uint32_t nj = (uint32_t)hjobs.size();
   if (nj == 0) return ZK_OK;
   const uint32_t B = 1u << (c - 1);
@@ -661,7 +869,8 @@ int msm_run_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs, uint32_t c) 
 }
 
 // prepare q scalar rows over the generator set g and append them as jobs (out[i] receives MSM i)
-int msm_enqueue(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_unmont, bool probe_bits, G1J* out, MsmQueue* queue, const uint32_t* out_idx) {
+int msm_enqueue(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_unmont, bool probe_bits, G1J* out, MsmQueue* queue, const uint32_t* out_idx,
+                const uint16_t* pattern) {
   const uint32_t n = g->n;
   if (q == 0) return ZK_OK;
   uint64_t total = (uint64_t)q * n;
@@ -673,6 +882,19 @@ int msm_enqueue(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_
   uint32_t bits = 254;
   if (probe_bits) {  // setup-time paths only (commit): one host round trip buys 10x fewer windows
     ZK_TRY(dev_to_host(ctx, &bits, maxbits.get(), 4));
+  }
+  if (!probe_bits && ctx->full_tables && g->full.pts && !ctx->msm_window) {  // full-width scalars over a prepared generator set: the bucket-free path
+    for (uint32_t i = 0; i < q; i++) {
+      MsmJobHost h{nullptr, mags.get() + (uint64_t)i * n, out + (out_idx ? out_idx[i] : i), g->full.W};
+      h.F = &g->full;
+      if (pattern && pattern[i] != 0x1fe && n >= 2) {
+        h.pat_r = (uint8_t)(pattern[i] >> 1);
+        h.pat_par = (uint8_t)(pattern[i] & 1u);
+      }
+      queue->jobs.push_back(h);
+    }
+    queue->keep.push_back(std::move(mags));
+    return ZK_OK;
   }
   uint32_t c = msm_pick_window(ctx, bits);
   uint32_t W = msm_num_windows(bits, c);
@@ -1082,13 +1304,20 @@ int me_open_flat_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32
   if (derive) {
     // deferred batch: [T_0,] every T0_r / T1_r and the final generator as MSMs; the T_r derived behind the batch
     std::vector<uint32_t> rows;
-    if (!from_com) rows.push_back(0);
+    std::vector<uint16_t> pat;  // T0_r only has scalars where bit r of the generator index is set, T1_r where it is clear (k_mo_scalars)
+    if (!from_com) {
+      rows.push_back(0);
+      pat.push_back(0x1fe);
+    }
     for (uint32_t r = 0; r < k; r++) {
       rows.push_back(3 * r + 1);
+      pat.push_back((uint16_t)((r << 1) | 1u));
       rows.push_back(3 * r + 2);
+      pat.push_back((uint16_t)((r << 1) | 0u));
     }
     rows.push_back(3 * k);
-    ZK_TRY(msm_enqueue(ctx, g, scal.get(), q, /*do_unmont=*/false, /*probe_bits=*/false, proof_d, queue, rows.data()));
+    pat.push_back(0x1fe);
+    ZK_TRY(msm_enqueue(ctx, g, scal.get(), q, /*do_unmont=*/false, /*probe_bits=*/false, proof_d, queue, rows.data(), pat.data()));
     DBuf<Fr> coef;
     if (!coef.alloc(ctx, (size_t)k * k)) return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: derive coefficients");
     ZK_LAUNCHB(ctx, "me_open_scalars", 32ull * k * k, 64, k_mo_derive_coef, dim3((k * k + 63) / 64), 0, u_d, k, from_com ? 0u : 1u, coef.get());
@@ -1096,8 +1325,20 @@ int me_open_flat_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32
     queue->keep.push_back(std::move(coef));
     return ZK_OK;
   }
-  if (queue) return msm_enqueue(ctx, g, scal.get(), q, /*do_unmont=*/false, /*probe_bits=*/false, proof_d, queue);
-  return msm_batch_dev(ctx, g, scal.get(), q, /*do_unmont=*/false, /*probe_bits=*/false, proof_d);
+  {
+    std::vector<uint16_t> pat;  // rows 3r, 3r + 1, 3r + 2 = T_r (dense), T0_r, T1_r; row 3k the final generator
+    for (uint32_t r = 0; r < k; r++) {
+      pat.push_back(0x1fe);
+      pat.push_back((uint16_t)((r << 1) | 1u));
+      pat.push_back((uint16_t)((r << 1) | 0u));
+    }
+    pat.push_back(0x1fe);
+    if (queue) return msm_enqueue(ctx, g, scal.get(), q, /*do_unmont=*/false, /*probe_bits=*/false, proof_d, queue, nullptr, pat.data());
+    MsmQueue own;
+    ZK_TRY(msm_enqueue(ctx, g, scal.get(), q, /*do_unmont=*/false, /*probe_bits=*/false, proof_d, &own, nullptr, pat.data()));
+    ZK_TRY(msm_flush(ctx, &own));
+    return g1_canonicalise_dev(ctx, proof_d, q);
+  }
 }
 
 // com(u): sum_i eq(unmont u, i) * P_i over the (precomputed) commitment points -- the MSM form of
