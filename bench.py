@@ -414,16 +414,16 @@ def main():
     ap.add_argument("--spinup-ms", type=float, default=400.0, help="untimed proofs before the W warm-up steps until this much wall time has passed: the first process on a "
                     "fresh box otherwise runs its first ~100 ms 12 %% slow (GPU power state); 0 disables")
     ap.add_argument("--prof-steps", type=int, default=2, help="proofs per event-profiled pass after the timed region (ZKDL_PROF_TRACE=<file> writes their per-launch timeline)")
-    ap.add_argument("--drain", type=int, default=1, help="the last N proofs of a run take the short G1 form (every round commitment an MSM instead of derived): "
+    ap.add_argument("--drain", type=int, default=-1, help="the last N proofs of a run take the short G1 form (every round commitment an MSM instead of derived): "
                     "they have no later proofs to hide the longer derived form under")
     ap.add_argument("--pair", type=int, default=1, choices=[1, 2], help="proofs submitted together (zk_transcript_seal_pair): 2 = the Fr phases of two consecutive "
                     "proofs share their launches; every proof is still its own batch-256 proof with its own transcript and digest row")
     ap.add_argument("--full-tables", type=int, default=12, help="window width of the precomputed digit tables of every layer's generators (zk_gens_prepare_full: "
                     "96 B x n_gens x windows x 2^(c-1): 62 GB for the 18M MLP at c = 12); the openings' MSMs then run without buckets; 0 = the bucket method only")
     ap.add_argument("--g1-streams", type=int, default=-1, help="G1 streams sealed proofs rotate over (-1: one when --g1-batch > 1, else the library's two)")
-    ap.add_argument("--g1-batch", type=int, default=2, help="sealed proofs whose G1 phases (MSM batch, derived round commitments, canonical form) run as ONE batch: "
+    ap.add_argument("--g1-batch", type=int, default=3, help="sealed proofs whose G1 phases (MSM batch, derived round commitments, canonical form) run as ONE batch: "
                     "the latency-bound launches behind the accumulation are shared (zk_set_flag g1_batch); a proof then waits for its partners")
-    ap.add_argument("--inflight", type=int, default=6, help="transcripts rotated by the pipelined loop (proofs whose G1 phase may still be running)")
+    ap.add_argument("--inflight", type=int, default=8, help="transcripts rotated by the pipelined loop (proofs whose G1 phase may still be running)")
     ap.add_argument("--no-derive", action="store_true", help="run every round commitment T_r of the openings as an MSM (library default) instead of deriving T_1.. from the "
                     "folding relation behind the MSM batch (the throughput configuration: -31 %% msm_accum work, a ~6 ms longer G1 phase per proof)")
     ap.add_argument("--serial", action="store_true", help="no worker streams at all: every launch runs alone (the schedule the roofline durations are measured under)")
@@ -600,6 +600,8 @@ def main():
     # Derived round commitments trade a longer G1 phase per proof (~11 ms instead of ~5) for less vector work: worth it while there
     # are later proofs to hide it under.  The LAST proofs of the run have none, so they take the short G1 phase (every T_r as an MSM):
     # the pipeline then drains in one MSM chain instead of two.
+    if args.drain < 0:
+        args.drain = max(1, args.g1_batch)        # the whole last G1 batch: one derived proof in it would keep the derivation on the batch's chain
     drain_from = args.steps - args.drain if derive else args.steps
     t0 = time.perf_counter()
     i = 0

@@ -137,15 +137,25 @@ int open_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, uint32_t tn, zk_gens* com, co
   const Fr* u_lo = u_d;
   const Fr* u_hi = u_d + k_lo;
   // com(u_hi): computed by the reference and dropped (commitment.cu:88); kept as timed work and
-  // recorded in the transcript
-  if (ctx->msm_mode == ZK_MSM_PIPPENGER) ZK_TRY(g1_me_msm_dev(ctx, com, u_hi, k_hi, com_eval_d, queue));
-  else ZK_TRY(g1_me_dev(ctx, com->pts, m, u_hi, k_hi, com_eval_d));
+  // recorded in the transcript.  With digit tables of the GENERATORS at hand (zk_gens_prepare_full) it is computed as the commitment of the
+  // row-folded tensor instead of as a multilinear evaluation over the commitment points: com_row = sum_j g_j unmont(t[row][j]) (commit_dev),
+  // so sum_row eq(u_hi, row) com_row = sum_j g_j unmont(folded_j) -- the same group element, one more MSM over the generators' tables, and no
+  // bucket-method job (over the commitment points' window tables) left in a proof.
+  const bool com_by_fold = ctx->msm_mode == ZK_MSM_PIPPENGER && queue && ctx->full_tables && g->full.pts && !ctx->msm_window;
+  if (com_by_fold) {
+    if (m != (1u << k_hi)) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
+  } else if (ctx->msm_mode == ZK_MSM_PIPPENGER) {
+    ZK_TRY(g1_me_msm_dev(ctx, com, u_hi, k_hi, com_eval_d, queue));
+  } else {
+    ZK_TRY(g1_me_dev(ctx, com->pts, m, u_hi, k_hi, com_eval_d));
+  }
   if (k_lo > 31 || n != (1u << k_lo)) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");  // commitment.cu:89
   uint32_t fsz = fr_partial_me_size(tn, k_hi, n);
   if (fsz != n) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   ZK_ALLOC(ctx, folded, Fr, n);
   if (tq && k_hi > 0) ZK_TRY(fr_partial_me_q16_dev(ctx, tq, tn, u_hi, k_hi, n, folded.get()));
   else ZK_TRY(fr_partial_me_dev(ctx, t, tn, u_hi, k_hi, n, folded.get()));
+  if (com_by_fold) ZK_TRY(msm_enqueue(ctx, g, folded.get(), 1, /*do_unmont=*/true, /*probe_bits=*/false, com_eval_d, queue));
   // com_eval_d (this call's com(u_hi), a slot of the same deferred batch) lets the derived-rounds form obtain T_0 = [R] com(u_hi) as well
   return me_open_dev(ctx, g, folded.get(), u_lo, k_lo, proof_d, ret_d, queue, ctx->msm_mode == ZK_MSM_PIPPENGER ? com_eval_d : nullptr);
 }

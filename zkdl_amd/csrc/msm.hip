@@ -665,8 +665,8 @@ __device__ __forceinline__ uint32_t pat_index(uint32_t t, uint32_t r, uint32_t p
   if (r >= 32u) return t;
   return ((t >> r) << (r + 1)) | (par << r) | (t & ((1u << r) - 1u));
 }
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZK_ACCUM_WAVES, ZK_ACCUM_WAVES))) k_msmf_accum(const FullJob* __restrict__ jobs, uint32_t c, RecodeK K,
-                                                                                                                    G1X* __restrict__ partial) {
+template <bool INL, int AHEAD>
+__device__ __forceinline__ void msmf_accum_body(const FullJob* __restrict__ jobs, uint32_t c, const RecodeK& K, G1X* __restrict__ partial) {
   const FullJob job = jobs[blockIdx.y];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t items = (uint64_t)job.nnz * job.W;
@@ -675,33 +675,67 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZK_ACCU
   const uint64_t e1 = e0 + MSM_CHUNK < items ? e0 + MSM_CHUNK : items;
   uint32_t pt = (uint32_t)(e0 / job.W), w = (uint32_t)(e0 - (uint64_t)pt * job.W);
   const uint32_t half_log = c - 1;
-  G1X acc = g1x_zero();
-  Recoded rc;
-  uint32_t i = 0;
-  bool live = false, fresh = true;
-  for (uint64_t e = e0; e < e1; e++) {
-    if (fresh) {
-      i = pat_index(pt, job.pat_r, job.pat_par);
-      live = !job.inf[i];
-      if (live) rc = recode_prepare(job.mags[i], K);
-      fresh = false;
-    }
-    if (live) {
-      bool neg;
-      const uint32_t d = recode_digit(rc, c, w, neg);
-      if (d) {
-        G1A P = job.tab[((((size_t)i * job.W + w)) << half_log) + (d - 1)];
-        if (neg) P.y = fp_neg(P.y);
-        acc = g1x_madd<ACCUM_INLINE>(acc, fq_unpack(P.x), fq_unpack(P.y));
+  // pass 1 (integer work only): the chunk's table offsets; bit 63 = negate, ~0 = nothing to add (digit 0, infinite base)
+  uint64_t offs[MSM_CHUNK];
+  {
+    Recoded rc;
+    uint32_t i = 0;
+    bool live = false, fresh = true;
+#pragma unroll
+    for (uint32_t s_ = 0; s_ < MSM_CHUNK; s_++) {
+      uint64_t o = ~0ull;
+      if (e0 + s_ < e1) {
+        if (fresh) {
+          i = pat_index(pt, job.pat_r, job.pat_par);
+          live = !job.inf[i];
+          if (live) rc = recode_prepare(job.mags[i], K);
+          fresh = false;
+        }
+        if (live) {
+          bool neg;
+          const uint32_t d = recode_digit(rc, c, w, neg);
+          if (d) o = (((((uint64_t)i * job.W + w)) << half_log) + (d - 1)) | (neg ? (1ull << 63) : 0ull);
+        }
+        if (++w == job.W) {
+          w = 0;
+          pt++;
+          fresh = true;
+        }
       }
+      offs[s_] = o;
     }
-    if (++w == job.W) {
-      w = 0;
-      pt++;
-      fresh = true;
+  }
+  // pass 2: the additions, each table entry requested AHEAD items early (random 96-byte reads from gigabytes: HBM latency, not L2)
+  G1X acc = g1x_zero();
+  G1A q[AHEAD];
+#pragma unroll
+  for (int a = 0; a < AHEAD; a++)
+    if (a < (int)MSM_CHUNK && offs[a] != ~0ull) q[a] = job.tab[offs[a] & ~(1ull << 63)];
+#pragma unroll
+  for (uint32_t s_ = 0; s_ < MSM_CHUNK; s_++) {
+    G1A P = q[s_ % AHEAD];
+    const uint64_t o = offs[s_];
+    if (s_ + AHEAD < MSM_CHUNK && offs[s_ + AHEAD] != ~0ull) q[s_ % AHEAD] = job.tab[offs[s_ + AHEAD] & ~(1ull << 63)];
+    if (o != ~0ull) {
+      if (o >> 63) P.y = fp_neg(P.y);
+      acc = g1x_madd<INL>(acc, fq_unpack(P.x), fq_unpack(P.y));
     }
   }
   partial[job.part_off + t] = acc;
+}
+// variants (ZKDL_FT_VARIANT, experiments): 0 = inlined products, 2 waves/SIMD, 1 entry ahead (default); 1 = two entries ahead; 2 = products as calls, 3 waves;
+// 3 = products as calls, 4 waves
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_msmf_accum(const FullJob* __restrict__ jobs, uint32_t c, RecodeK K, G1X* __restrict__ partial) {
+  msmf_accum_body<true, 1>(jobs, c, K, partial);
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_msmf_accum_v1(const FullJob* __restrict__ jobs, uint32_t c, RecodeK K, G1X* __restrict__ partial) {
+  msmf_accum_body<true, 2>(jobs, c, K, partial);
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) k_msmf_accum_v2(const FullJob* __restrict__ jobs, uint32_t c, RecodeK K, G1X* __restrict__ partial) {
+  msmf_accum_body<false, 1>(jobs, c, K, partial);
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_msmf_accum_v3(const FullJob* __restrict__ jobs, uint32_t c, RecodeK K, G1X* __restrict__ partial) {
+  msmf_accum_body<false, 2>(jobs, c, K, partial);
 }
 __global__ void __launch_bounds__(256) k_msmf_reduce(const FullJob* __restrict__ jobs, const G1X* __restrict__ partial) {
   __shared__ G1X sm[4];
@@ -785,7 +819,12 @@ static int msm_run_full_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs) 
     else ZK_TRY(host_to_dev(ctx, djobs.get(), jobs.data(), bytes));
   }
   ZK_ALLOC(ctx, partial, G1X, parts);
-  ZK_LAUNCH(ctx, "msm_table_accum", 100ull * items_all, k_msmf_accum, dim3((max_lanes + 63) / 64, nj), dim3(64), 0, (const FullJob*)djobs.get(), c, K, partial.get());
+  static const int variant = [] { const char* e = getenv("ZKDL_FT_VARIANT"); return e ? atoi(e) : 0; }();
+  const dim3 grid((max_lanes + 63) / 64, nj);
+  if (variant == 1) ZK_LAUNCH(ctx, "msm_table_accum", 100ull * items_all, k_msmf_accum_v1, grid, dim3(64), 0, (const FullJob*)djobs.get(), c, K, partial.get());
+  else if (variant == 2) ZK_LAUNCH(ctx, "msm_table_accum", 100ull * items_all, k_msmf_accum_v2, grid, dim3(64), 0, (const FullJob*)djobs.get(), c, K, partial.get());
+  else if (variant == 3) ZK_LAUNCH(ctx, "msm_table_accum", 100ull * items_all, k_msmf_accum_v3, grid, dim3(64), 0, (const FullJob*)djobs.get(), c, K, partial.get());
+  else ZK_LAUNCH(ctx, "msm_table_accum", 100ull * items_all, k_msmf_accum, grid, dim3(64), 0, (const FullJob*)djobs.get(), c, K, partial.get());
   ZK_LAUNCH(ctx, "msm_table_sum", (uint64_t)sizeof(G1X) * parts, k_msmf_reduce, dim3(nj), dim3(256), 0, (const FullJob*)djobs.get(), (const G1X*)partial.get());
   return ZK_OK;
 }
