@@ -191,11 +191,19 @@ def test_demo_driver_at_the_headline_configuration(tmp_path):
     run2 = subprocess.run([exe, model_pt, input_pt, "--fs", "--verify", "--repeat", "1"], capture_output=True, text=True, cwd=d, timeout=900)
     assert run2.returncode == 0, run2.stdout + run2.stderr
     assert "Verification: OK" in run2.stdout and "Total number of parameters: 18247968" in run2.stdout
+    # the same with digit tables of the generators (setup: 62 GB): same demo.out, verifies, faster
+    run3 = subprocess.run([exe, model_pt, input_pt, "--fs", "--verify", "--repeat", "3", "--full-tables", "12"], capture_output=True, text=True, cwd=d, timeout=900)
+    assert run3.returncode == 0, run3.stdout + run3.stderr
+    assert "Verification: OK" in run3.stdout
+    warm3 = float(re.search(r"Warm proof time: ([0-9.eE+-]+) seconds per data point", run3.stdout).group(1))
+    assert 0 < warm3 < 0.1
+    assert [int(x, 16) for x in open(os.path.join(d, "demo.out")).read().strip().strip("[]").split("\n")] == vals
     keep = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(keep):
         with open(os.path.join(keep, "demo_headline.txt"), "w") as f:
             f.write("$ python -m zkdl_amd.model && ./demo traced_model.pt sample_input.pt --seed 5 --repeat 3\n" + run.stdout)
             f.write("\n$ ./demo traced_model.pt sample_input.pt --fs --verify --repeat 1\n" + run2.stdout)
+            f.write("\n$ ./demo traced_model.pt sample_input.pt --fs --verify --repeat 3 --full-tables 12\n" + run3.stdout)
 
 
 def test_demo_loads_leaky_identity_and_bare_linear_stacks(tmp_path):

@@ -1,5 +1,5 @@
 // zkdl_amd/host/demo.cpp -- the reference driver (demo.cu) on the MI355X library.
-//   ./demo traced_model.pt sample_input.pt [--seed S] [--dump DIR] [--fs] [--verify] [--repeat N] [--gpus N] [--dist]
+//   ./demo traced_model.pt sample_input.pt [--seed S] [--dump DIR] [--fs] [--verify] [--repeat N] [--gpus N] [--dist] [--full-tables C]
 // Same CLI, same inputs (TorchScript nn.Sequential of bias-free Linear + ReLU; a tensor saved as
 // parameter "0" of a scripted empty module, model.py:4-8), same outputs: demo.out (Y_hat, one
 // 0x%064x per line, demo.cu:119-122) and the three stdout lines (demo.cu:92,140-141).
@@ -12,6 +12,8 @@
 // only public data (generators, commitments, the input and output tensors), and prints "Verification: OK" or the failed check.
 // --repeat N proves the same statement N more times after the reference's single (cold: first-use allocations, window tables)
 // timed loop and prints the best of them as "Warm proof time: ..." -- the transcript kept is the first run's.
+// --full-tables C: digit tables of every layer's generators (zk_gens_prepare_full, window C bits; 62 GB for the 18M MLP at C = 12), built with the
+// commitments (setup); the openings' MSMs then need no buckets.
 // --gpus N (N > 1): this process starts N copies of itself, one per GPU (ZKDL_RANK / ZKDL_WORLD / ZKDL_DEVICE in their environment), BEFORE it
 // touches the GPU; every rank proves the statement on its own device with its own generator seed (independent proof batches: north_star's
 // multi-GPU layout), and the ranks' transcript digests are summed by ONE RCCL all-reduce over xGMI (zk_dist_*: no torch.distributed); rank 0
@@ -80,6 +82,7 @@ torch::Tensor load_tensor(const string& path) {   // demo.cu:40-46
 struct Act {
   uint kind = 0, shift = 0;
 };
+static uint g_full_tables = 0;   // --full-tables C
 static Act activation_of(const torch::jit::script::Module& child) {
   const string type = child.type()->name() ? child.type()->name()->qualifiedName() : string();
   Act a;
@@ -155,6 +158,7 @@ vector<zkFC> load_model(const string& model_path, vector<unique_ptr<Commitment>>
     generators.emplace_back(new Commitment(1U << ((ceilLog2(in_dim * out_dim) + 1) / 2), G1Jacobian_generator));   // demo.cu:81
     *generators.back() *= FrTensor::random(generators.back()->size);                                               // demo.cu:82
     fcs.push_back(zkFC::from_float_gpu_ptr(in_dim, out_dim, w.p, *generators.back()));
+    if (g_full_tables) generators.back()->prepare_full(g_full_tables);
     if (fcs.size() > 1 && fcs[fcs.size() - 2].outputSize != fcs[fcs.size() - 1].inputSize) throw std::runtime_error("Incompatible layer sizes");
   }
   cout << "Total number of parameters: " << parameter_count << endl;
@@ -202,6 +206,7 @@ int main(int argc, char* argv[]) {
   for (int i = 3; i < argc; i++) {
     if (string(argv[i]) == "--gpus" && i + 1 < argc) gpus = atoi(argv[i + 1]);
     if (string(argv[i]) == "--dist") dist = true;
+    if (string(argv[i]) == "--full-tables" && i + 1 < argc) g_full_tables = (uint)atoi(argv[i + 1]);
   }
   const char* rank_env = getenv("ZKDL_RANK");
   if (gpus > 1 && !rank_env) return spawn_ranks(gpus, argv);

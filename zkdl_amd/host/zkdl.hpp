@@ -414,6 +414,9 @@ class Commitment : public G1TensorJacobian {
   using G1TensorJacobian::operator*=;
   Commitment(const Commitment& c) : G1TensorJacobian(c) {}
   ~Commitment() override { if (handle_) zk_gens_destroy(handle_); }
+  // additive: precompute every signed digit of every window of these generators (zk_gens_prepare_full): full-width MSMs over them -- the
+  // openings of zkFC::prove -- then run without buckets.  Setup, like the commitments; the points must not be mutated afterwards.
+  void prepare_full(uint window_bits = 12) const { zkdl::check(zk_gens_prepare_full(zkdl::ctx(), handle(), window_bits)); }
   // generator handle (snapshot of the current points + their MSM window tables), rebuilt after mutation
   zk_gens* handle() const {
     if (!handle_ || handle_version_ != version_) {
