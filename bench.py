@@ -88,7 +88,7 @@ class Workload:
                 g.prepare_full(full_tables)
                 zk.sync()
                 t_full += time.perf_counter() - t0
-                full_bytes += 96 * s["n_gens"] * ((254 + 2 + full_tables - 1) // full_tables) * (1 << (full_tables - 1))
+                full_bytes += 128 * s["n_gens"] * ((254 + 2 + full_tables - 1) // full_tables) * (1 << (full_tables - 1))
             w = rng.uniform(-1.0 / np.sqrt(s["n_in"]), 1.0 / np.sqrt(s["n_in"]), size=(s["n_in"], s["n_out"])).astype(np.float32)
             wd = zk.upload_f32(w)
             zk.sync()
@@ -419,7 +419,7 @@ def main():
     ap.add_argument("--pair", type=int, default=1, choices=[1, 2], help="proofs submitted together (zk_transcript_seal_pair): 2 = the Fr phases of two consecutive "
                     "proofs share their launches; every proof is still its own batch-256 proof with its own transcript and digest row")
     ap.add_argument("--full-tables", type=int, default=12, help="window width of the precomputed digit tables of every layer's generators (zk_gens_prepare_full: "
-                    "96 B x n_gens x windows x 2^(c-1): 62 GB for the 18M MLP at c = 12); the openings' MSMs then run without buckets; 0 = the bucket method only")
+                    "128 B x n_gens x windows x 2^(c-1): 83 GB for the 18M MLP at c = 12); the openings' MSMs then run without buckets; 0 = the bucket method only")
     ap.add_argument("--g1-streams", type=int, default=-1, help="G1 streams sealed proofs rotate over (-1: one when --g1-batch > 1, else the library's two)")
     ap.add_argument("--g1-batch", type=int, default=3, help="sealed proofs whose G1 phases (MSM batch, derived round commitments, canonical form) run as ONE batch: "
                     "the latency-bound launches behind the accumulation are shared (zk_set_flag g1_batch); a proof then waits for its partners")
@@ -800,13 +800,14 @@ def main():
         macs_per_step["msm_table_sum"] = ft_pairs * W_ft / 16.0 * 14 * FP_MACS
         fam["msm_table_accum"] = (["k_msmf_accum"], 100, None)
         fam["msm_table_sum"] = (["k_msmf_reduce"], None, None)
-    if "msm_accum" in prof and args.msm == "pippenger":
-        c_win, W_win, chunk = (args.msm_window or 10), None, 16
+    if args.msm == "pippenger":
+        c_win, chunk = (args.msm_window or 10), 16
         W_win = (254 + 2 + c_win - 1) // c_win
-        slots = prof["msm_accum"]["bytes"] / 100.0 / nprof
-        bucket_pairs = sum(s_["m"] for s_ in wl.shapes) if ft_on else real_pairs
+        has_bucket = "msm_accum" in prof
+        slots = (prof["msm_accum"]["bytes"] / 100.0 / nprof) if has_bucket else 0.0
+        bucket_pairs = 0 if (ft_on and not has_bucket) else (sum(s_["m"] for s_ in wl.shapes) if ft_on else real_pairs)
         items = min(slots, bucket_pairs * float(W_win))
-        n_jobs = len(klo) if ft_on else sum((2 * k_ + 2) if derive else (3 * k_ + 2) for k_ in klo)   # MSMs on the bucket path (derived: T0_r, T1_r, final generator, com(u_hi))
+        n_jobs = 0 if not has_bucket else (len(klo) if ft_on else sum((2 * k_ + 2) if derive else (3 * k_ + 2) for k_ in klo))   # MSMs on the bucket path
         B = 1 << (c_win - 1)
         LB = c_win // 2
         nlo, nhi = 1 << LB, (B >> LB) + 1
@@ -815,13 +816,14 @@ def main():
         n_derived = sum(k_ * k_ for k_ in klo) if derive else 0                       # coef * point products behind the batch (T_0 .. T_{k-1}: 2r + 1 each)
         n_g1_out = sum(3 * k_ + 2 for k_ in klo)                                      # transcript points put into canonical form
         g1_model = {"bucket_items": items, "bucket_jobs": n_jobs, "derived_products": n_derived, "points_canonicalised": n_g1_out, "window_bits": c_win, "windows": W_win,
-                    "table_items": (ft_pairs * W_ft if ft_on else 0), "table_window_bits": (wl.full_tables if ft_on else None)}
-        macs_per_step["msm_accum"] = items * MADD * FP_MACS
-        # stitching: a bucket that spans chunks t0..t1 costs t1 - t0 additions: in total one per chunk boundary that falls inside a bucket (~ all of them)
-        macs_per_step["msm_combine"] = max(items / chunk - n_jobs, 0.0) * ADD * FP_MACS
-        macs_per_step["msm_bucket_reduce"] = 2.0 * B * n_jobs * ADD * FP_MACS         # every bucket enters one row sum and one column sum
-        # per MSM: c bit-slices of the row / column sums (half of the sums each), sum_j j doublings, a 15-addition tree, back to Jacobian (6 products)
-        macs_per_step["msm_horner"] = n_jobs * ((LB * (nlo // 2) + (c_win - LB) * ((nhi - 1) // 2) + 15) * ADD + (c_win * (c_win - 1) // 2) * DBL + 6) * FP_MACS
+                    "table_items": (ft_pairs * W_ft if ft_on else 0), "table_window_bits": (wl.full_tables if ft_on else None), "real_pairs": real_pairs}
+        if has_bucket:
+            macs_per_step["msm_accum"] = items * MADD * FP_MACS
+            # stitching: a bucket that spans chunks t0..t1 costs t1 - t0 additions: in total one per chunk boundary that falls inside a bucket (~ all of them)
+            macs_per_step["msm_combine"] = max(items / chunk - n_jobs, 0.0) * ADD * FP_MACS
+            macs_per_step["msm_bucket_reduce"] = 2.0 * B * n_jobs * ADD * FP_MACS     # every bucket enters one row sum and one column sum
+            # per MSM: c bit-slices of the row / column sums (half of the sums each), sum_j j doublings, a 15-addition tree, back to Jacobian (6 products)
+            macs_per_step["msm_horner"] = n_jobs * ((LB * (nlo // 2) + (c_win - LB) * ((nhi - 1) // 2) + 15) * ADD + (c_win * (c_win - 1) // 2) * DBL + 6) * FP_MACS
         if n_derived and "msm_derive" in prof:
             # per product: GLV halves on two lanes, each 128 doublings + 32 window additions + an 8-entry table (1 doubling + 6 additions); the halves' sum;
             # then one addition per product into its T_r
@@ -896,7 +898,7 @@ def main():
            "host_enqueue_ms_per_step": t_enq * 1e3 / max(args.steps, 1), "aggregate_fr": hex(aggregate), "setup": wl.info, "roofline": roofline,
            "roofline_chip_filling": roofline_fill, "roofline_all": roofline_all, "g1_model": g1_model, "kernels": kernels,
            "g1_msm_mops_commit": wl.info["commit_mops"]}
-    if "msm_accum" in prof:
+    if "msm_accum" in prof or "msm_table_accum" in prof:
         g1_ms = sum(prof[k]["ms"] for k in prof if (k.startswith("msm_") and k != "msm_fulltable_build") or k == "g1_canonicalise") / nprof
         out["g1_msm_mops_prove"] = real_pairs / g1_ms / 1e3 if g1_ms > 0 else None   # nonzero full-width (point, scalar) pairs of one proof / its G1 kernels' time
     if rank == 0 and not args.no_msm_probe and args.workload.startswith("mlp18m"):

@@ -167,8 +167,8 @@ int zk_set_flag(zk_ctx* ctx, const char* name, int value);
 int zk_gens_create(zk_ctx* ctx, const zk_g1j* gens_d, uint32_t n, zk_gens** out);
 int zk_gens_destroy(zk_gens* g);
 /* Optional setup step for generator sets that will see many full-width MSMs (the openings of zk_fc_prove, zk_act_open, zk_msm_batch): precompute
- * EVERY signed digit of every window, d * 2^(c w) * G_j for d = 1 .. 2^(c-1) (c = window_bits, 4 .. 14; 22 windows at c = 12: 4.3 MB per
- * generator, 8.9 GB for 2048 generators -- sized for 288 GB of HBM).  Full-width MSMs over this handle then run without buckets: mixed
+ * EVERY signed digit of every window, d * 2^(c w) * G_j for d = 1 .. 2^(c-1) (c = window_bits, 4 .. 14; 22 windows at c = 12, one 128-byte slot per entry: 5.8 MB per
+ * generator, 11.8 GB for 2048 generators -- sized for 288 GB of HBM).  Full-width MSMs over this handle then run without buckets: mixed
  * additions of table entries and one sum of lane partials per MSM (no sort, no bucket reduction, 22 instead of 26 windows).  Same group
  * elements.  Commitments of quantised tensors (short scalars) keep the bucket method.  The flag "full_tables" (default 1) turns the path off
  * without freeing the tables. */

@@ -191,7 +191,7 @@ def test_demo_driver_at_the_headline_configuration(tmp_path):
     run2 = subprocess.run([exe, model_pt, input_pt, "--fs", "--verify", "--repeat", "1"], capture_output=True, text=True, cwd=d, timeout=900)
     assert run2.returncode == 0, run2.stdout + run2.stderr
     assert "Verification: OK" in run2.stdout and "Total number of parameters: 18247968" in run2.stdout
-    # the same with digit tables of the generators (setup: 62 GB): same demo.out, verifies, faster
+    # the same with digit tables of the generators (setup: 83 GB): same demo.out, verifies, faster
     run3 = subprocess.run([exe, model_pt, input_pt, "--fs", "--verify", "--repeat", "3", "--full-tables", "12"], capture_output=True, text=True, cwd=d, timeout=900)
     assert run3.returncode == 0, run3.stdout + run3.stderr
     assert "Verification: OK" in run3.stdout

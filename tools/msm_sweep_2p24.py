@@ -47,8 +47,27 @@ def main():
         rows.append(rec)
         print("c=%2d   full-width 2^24 pairs: %8.2f ms  %7.1f Mpairs/s     quantised commit: %7.2f ms  %7.1f Mpairs/s" %
               (c, rec["fullwidth_msm_batch_ms"], rec["fullwidth_msm_batch_mops"], rec["quantised_commit_ms"], rec["quantised_commit_mops"]), flush=True)
+    # the bucket-free path: every signed digit of every window precomputed (zk_gens_prepare_full); same group elements
+    zk.set_msm_window(0)
+    table_rows = []
+    for c in (8, 10, 11, 12, 13):
+        g2 = zk.gens(gens.points())
+        g2.prepare_full(c)
+        zk.sync()
+        out = zk.msm_batch(g2, full)
+        zk.sync()
+        zk.timer_start()
+        out = zk.msm_batch(g2, full)
+        ms = zk.timer_stop_ms()
+        aff, inf = zk.g1_to_affine(out.view(0, 64))
+        assert (aff.tobytes(), inf.tobytes()) == ref_full, "digit tables of width %d change the MSM result" % c
+        table_gb = 128.0 * n * ((256 + c - 1) // c) * (1 << (c - 1)) / 1e9
+        table_rows.append({"window": c, "fullwidth_msm_batch_ms": ms, "fullwidth_msm_batch_mops": n * q / ms / 1e3, "table_gb": table_gb})
+        print("digit tables c=%2d (%.1f GB)   full-width 2^24 pairs: %8.2f ms  %7.1f Mpairs/s" % (c, table_gb, ms, n * q / ms / 1e3), flush=True)
+        del out
+        g2.close()
     if "--json" in sys.argv:
-        json.dump({"pairs": n * q, "n_gens": n, "rows": q, "sweep": rows}, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
+        json.dump({"pairs": n * q, "n_gens": n, "rows": q, "sweep": rows, "digit_tables": table_rows}, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
     zk.close()
 
 

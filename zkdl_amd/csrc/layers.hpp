@@ -11,9 +11,13 @@ struct G1Table {  // affine window table: pts[w*n + j] = 2^(c*w) * base_j ; inf[
 }  // namespace zk
 
 namespace zk {
+struct alignas(128) G1AE {  // one table entry: 96 bytes of affine point in a 128-byte slot, so that a (random) read touches exactly one 128-byte line
+  G1A p;
+  uint32_t pad[8];
+};
 struct G1FullTable {  // every signed digit of every window precomputed: pts[((j * W + w) << (c - 1)) + (d - 1)] = d * 2^(c w) * base_j, d = 1 .. 2^(c-1)
   uint32_t n = 0, c = 0, W = 0;
-  G1A* pts = nullptr;       // affine, the bucket pipeline's Montgomery domain (fq28.hpp); 96 B x n x W x 2^(c-1)
+  G1AE* pts = nullptr;      // affine, the bucket pipeline's Montgomery domain (fq28.hpp); 128 B x n x W x 2^(c-1)
   const uint8_t* inf = nullptr;  // [n] base-at-infinity flags (the window table's)
 };
 struct MsmJobHost {  // one pending MSM: *out = sum_j mags[j] * base_j over table T (W windows in use)

@@ -594,17 +594,18 @@ uint32_t msm_num_windows(uint32_t bits, uint32_t c) {
 
 // ------------------------------------------------------------------ the bucket-free path: full digit tables
 // The generators of a layer never change, and 288 GB of HBM hold a lot of table: with EVERY signed digit of every window precomputed
-// (d * 2^(c w) * G_j for d = 1 .. 2^(c-1): at c = 12, 22 windows x 2048 entries x 96 B = 4.3 MB per generator, 8.9 GB per 2048-generator
-// layer) an MSM is nothing but mixed additions of table entries: no buckets, so no sort, no stitching of chunk partials, no row / column /
+// (d * 2^(c w) * G_j for d = 1 .. 2^(c-1): at c = 12, 22 windows x 2048 entries x 128 B = 5.8 MB per generator, 11.8 GB per 2048-generator
+// layer; an entry is 96 bytes in a 128-byte slot, so that a read touches one 128-byte line -- unpadded, the entries straddled lines and the
+// accumulation fetched 2.4x its algorithmic bytes) an MSM is nothing but mixed additions of table entries: no buckets, so no sort, no stitching of chunk partials, no row / column /
 // weighted bucket reduction -- and 22 windows instead of 26.  Per proof of the 18M-parameter MLP: 4.3 M mixed additions + 0.27 M additions of
 // lane partials, against 5.1 M + ~0.7 M additions in three latency-bound reduction launches on the bucket path.  The table reads are random
-// 96-byte accesses into gigabytes: ~0.6 GB of HBM traffic per proof, which the accumulation's arithmetic hides.
+// one-line accesses into gigabytes: ~0.6 GB of HBM traffic per proof, which the accumulation's arithmetic hides.
 //   k_fulltable_build  one lane per (generator, window) row: 2^(c-1) - 1 chained mixed additions, put into affine form 64 at a time with one
 //                      shared inversion (Montgomery's trick); setup, ~0.1 s per layer
 //   k_msmf_accum       each lane adds MSM_CHUNK consecutive (point, window) items of one job (point-major: a lane recodes a scalar once)
 //   k_msmf_reduce      one workgroup per job sums the lanes' partials (a few chained additions per lane, then a shuffle / LDS tree)
 struct FullJob {
-  const G1A* tab;
+  const G1AE* tab;
   const uint8_t* inf;
   const Fr* mags;
   G1J* out;
@@ -614,7 +615,7 @@ struct FullJob {
 };
 static constexpr uint32_t FT_SEG = 64;  // points put into affine form per shared inversion
 __global__ void __launch_bounds__(64) k_fulltable_build(const G1A* __restrict__ win, const uint8_t* __restrict__ inf, uint32_t n, uint32_t W, uint32_t half,
-                                                         G1A* __restrict__ out, G1X* __restrict__ scratch, Fq* __restrict__ prefix) {
+                                                         G1AE* __restrict__ out, G1X* __restrict__ scratch, Fq* __restrict__ prefix) {
   __shared__ Fq wtab[16 * 64];
   const uint32_t row = blockIdx.x * 64u + threadIdx.x;  // row = j * W + w
   if (row >= n * W) return;
@@ -624,7 +625,7 @@ __global__ void __launch_bounds__(64) k_fulltable_build(const G1A* __restrict__ 
   const Fq bx = fq_unpack(B.x), by = fq_unpack(B.y);
   G1X* sc = scratch + (size_t)row * FT_SEG;
   Fq* pr = prefix + (size_t)row * FT_SEG;
-  G1A* dst = out + (size_t)row * half;
+  G1AE* dst = out + (size_t)row * half;
   G1X acc = g1x_zero();
   for (uint32_t d0 = 0; d0 < half; d0 += FT_SEG) {
     const uint32_t cnt = half - d0 < FT_SEG ? half - d0 : FT_SEG;
@@ -655,7 +656,7 @@ __global__ void __launch_bounds__(64) k_fulltable_build(const G1A* __restrict__ 
       G1A o;
       o.x = cx;
       o.y = cy;
-      dst[d0 + i] = o;
+      dst[d0 + i].p = o;
     }
   }
 }
@@ -710,12 +711,12 @@ __device__ __forceinline__ void msmf_accum_body(const FullJob* __restrict__ jobs
   G1A q[AHEAD];
 #pragma unroll
   for (int a = 0; a < AHEAD; a++)
-    if (a < (int)MSM_CHUNK && offs[a] != ~0ull) q[a] = job.tab[offs[a] & ~(1ull << 63)];
+    if (a < (int)MSM_CHUNK && offs[a] != ~0ull) q[a] = job.tab[offs[a] & ~(1ull << 63)].p;
 #pragma unroll
   for (uint32_t s_ = 0; s_ < MSM_CHUNK; s_++) {
     G1A P = q[s_ % AHEAD];
     const uint64_t o = offs[s_];
-    if (s_ + AHEAD < MSM_CHUNK && offs[s_ + AHEAD] != ~0ull) q[s_ % AHEAD] = job.tab[offs[s_ + AHEAD] & ~(1ull << 63)];
+    if (s_ + AHEAD < MSM_CHUNK && offs[s_ + AHEAD] != ~0ull) q[s_ % AHEAD] = job.tab[offs[s_ + AHEAD] & ~(1ull << 63)].p;
     if (o != ~0ull) {
       if (o >> 63) P.y = fp_neg(P.y);
       acc = g1x_madd<INL>(acc, fq_unpack(P.x), fq_unpack(P.y));
@@ -771,11 +772,11 @@ int gens_prepare_full(zk_ctx* ctx, zk_gens* g, uint32_t c) {
   F.c = c;
   F.W = W;
   F.inf = T->inf;
-  if (dev_alloc(ctx, (void**)&F.pts, total * sizeof(G1A)) != hipSuccess) return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: full digit table");
+  if (dev_alloc(ctx, (void**)&F.pts, total * sizeof(G1AE)) != hipSuccess) return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: full digit table");
   {
     ZK_ALLOC(ctx, scratch, G1X, rows * FT_SEG);
     ZK_ALLOC(ctx, prefix, Fq, rows * FT_SEG);
-    ZK_LAUNCH(ctx, "msm_fulltable_build", (uint64_t)sizeof(G1A) * total, k_fulltable_build, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, (const G1A*)T->pts, (const uint8_t*)T->inf,
+    ZK_LAUNCH(ctx, "msm_fulltable_build", (uint64_t)sizeof(G1AE) * total, k_fulltable_build, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, (const G1A*)T->pts, (const uint8_t*)T->inf,
               g->n, W, half, F.pts, scratch.get(), prefix.get());
   }
   g->full = F;

@@ -12,7 +12,7 @@
 // only public data (generators, commitments, the input and output tensors), and prints "Verification: OK" or the failed check.
 // --repeat N proves the same statement N more times after the reference's single (cold: first-use allocations, window tables)
 // timed loop and prints the best of them as "Warm proof time: ..." -- the transcript kept is the first run's.
-// --full-tables C: digit tables of every layer's generators (zk_gens_prepare_full, window C bits; 62 GB for the 18M MLP at C = 12), built with the
+// --full-tables C: digit tables of every layer's generators (zk_gens_prepare_full, window C bits; 83 GB for the 18M MLP at C = 12), built with the
 // commitments (setup); the openings' MSMs then need no buckets.
 // --gpus N (N > 1): this process starts N copies of itself, one per GPU (ZKDL_RANK / ZKDL_WORLD / ZKDL_DEVICE in their environment), BEFORE it
 // touches the GPU; every rank proves the statement on its own device with its own generator seed (independent proof batches: north_star's
