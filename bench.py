@@ -291,8 +291,9 @@ def msm_fullwidth_probe(zk, log_pairs=24, full_tables=0):
     if full_tables:
         g.prepare_full(full_tables)
     sc = zk.fr_random(n * q)
-    out = zk.msm_batch(g, sc.view(0, n * min(q, 64)))           # builds the window tables, warms the pools
+    out = zk.msm_batch(g, sc)                                   # builds the window tables, sizes the pools (the lane partials of 8192 MSMs are gigabytes)
     zk.sync()
+    del out
     zk.timer_start()
     out = zk.msm_batch(g, sc)
     ms = zk.timer_stop_ms()
