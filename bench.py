@@ -607,8 +607,11 @@ def main():
     t0 = time.perf_counter()
     i = 0
     while i < args.steps:
-        if derive and i >= drain_from:
+        if derive and i == drain_from:
+            # the run's last proofs have no later proof to hide a long G1 chain under: short form (every round commitment an MSM), and each one's
+            # G1 phase on its own as soon as its Fr phase is submitted, so that only the very last proof's G1 chain is left when the Fr work ends
             zk.lib.zk_set_flag(zk.ctx, b"derive_rounds", 0)
+            zk.lib.zk_set_flag(zk.ctx, b"g1_batch", 1)
         if paired and i + 1 < args.steps:
             step2(i, rows_base + 64 * i, i + 1, rows_base + 64 * (i + 1))
             i += 2
@@ -624,6 +627,7 @@ def main():
     elapsed = time.perf_counter() - t0
     gc.enable()
     zk.set_flag("derive_rounds", 1 if derive else 0)
+    zk.set_flag("g1_batch", max(1, args.g1_batch))
     per_rank_ms = [elapsed * 1e3 / max(args.steps, 1)]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -891,7 +895,7 @@ def main():
                       "msm": args.msm, "derive_rounds": bool(derive), "inflight": args.inflight, "g1_batch": args.g1_batch, "g1_streams": (g1_streams or 2), "full_table_window_bits": ft, "proofs_per_submission": 2 if paired else 1, "prewarm_process": not args.no_prewarm,
                       "drain_form_proofs": (min(args.drain, args.steps) if derive else 0), "spinup_ms": args.spinup_ms, "spinup_proofs": n_spin,
                       "warmup_drain_form_proofs": (min(2, args.warmup) if derive and args.warmup >= 2 else 0),
-                      "schedule_note": "the last drain_form_proofs proofs of the timed region run every round commitment as an MSM (derive_rounds off): they have no later proof to hide the derivation under"},
+                      "schedule_note": "the last drain_form_proofs proofs of the timed region run every round commitment as an MSM (derive_rounds off) and their G1 phases unbatched (g1_batch 1): they have no later proof to hide a long G1 chain under"},
            "ms_per_proof": ms_per_step, "steady_state_ms_per_proof": (steady["ms_per_proof"] if steady else None), "steady_state": steady,
            "latency_ms_per_proof": (min(v["median_ms"] for v in latency.values() if isinstance(v, dict)) if latency else None), "latency": latency, "extensions": extensions,
            "per_rank_ms_per_proof": per_rank_ms, "collective_world_size": (dist.get_world_size() if world > 1 else 1),

@@ -669,3 +669,46 @@ def test_transcript_serialisation_round_trip(zk, oracle):
         blobs.append(blob)
     zk.set_flag("batch_layers", 1)
     assert blobs[0] == blobs[1]
+
+
+# ---- larger oracle sizes on the G1 paths: g1_me at 256 / 300 points, the flattened opening at 512 generators
+# (bucket method and digit tables), zk_open with 256 generators x 128 rows
+@pytest.mark.parametrize("n", [256, 300])
+def test_g1_me_against_the_oracle_at_hundreds_of_points(zk, oracle, rng, n):
+    pts = rand_points(oracle, rng, n)
+    k = (n - 1).bit_length()                                  # n in (2^(k-1), 2^k]  (g1-tensor.cu:489)
+    u = rand_fr(rng, k)
+    got = zk.g1_me(zk.upload(pts), u)
+    want = oracle.g1_me(pts, u)
+    assert eq(got.reshape(1, 36), np.asarray(want).reshape(1, 36))          # literal chain: Jacobian limbs equal
+
+
+@pytest.mark.parametrize("tables", [0, 6])
+def test_me_open_and_open_against_the_oracle_at_512_generators(zk, oracle, rng, tables):
+    from zkdl_amd.capi import MSM_PIPPENGER
+    zk.set_msm_mode(MSM_PIPPENGER)
+    n, k = 512, 9
+    gens = rand_points(oracle, rng, n)
+    dg = zk.gens(zk.upload(gens))
+    if tables:
+        dg.prepare_full(tables)
+    t, u = rand_fr(rng, n), rand_fr(rng, k)
+    ret, proof = zk.me_open(zk.upload(t), dg, u)
+    wret, wproof = oracle.me_open(t, gens, u)
+    assert eq(ret, wret)
+    ga, gi = affine_of(oracle, proof)
+    wa, wi = affine_of(oracle, wproof)
+    assert eq(ga, wa) and eq(gi, wi)
+    # Commitment::open over 64 rows of these generators
+    m = 64
+    w = small_signed_fr(oracle, rng, n * m)
+    com = zk.commit(dg, zk.upload(w))
+    want_com = oracle.commit(gens, w)
+    u2 = rand_fr(rng, k + 6)
+    ret, ce, proof = zk.open(dg, zk.upload(w), com, u2)
+    wret, wce, wproof = oracle.open(gens, w, want_com, u2)
+    assert eq(ret, wret)
+    for g, ww in ((ce, wce), (proof, wproof)):
+        ga, gi = affine_of(oracle, g)
+        wa, wi = affine_of(oracle, ww)
+        assert eq(ga, wa) and eq(gi, wi)

@@ -424,7 +424,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZK_ACCU
     }
     uint32_t it = items[p];
     uint32_t j = it & 0xfffffu, w = (it >> 20) & 0x7ffu;
-    G1A P = job.table[(uint64_t)w * job.n + j];
+    G1A P;
+    {
+      const __attribute__((address_space(1))) uint32_t* src = (const __attribute__((address_space(1))) uint32_t*)&job.table[(uint64_t)w * job.n + j];
+#pragma unroll
+      for (int l = 0; l < 12; l++) {
+        P.x.v[l] = src[l];
+        P.y.v[l] = src[12 + l];
+      }
+    }
     if (it >> 31) P.y = fp_neg(P.y);
     acc = g1x_madd<ACCUM_INLINE>(acc, fq_unpack(P.x), fq_unpack(P.y));
   }
@@ -666,6 +674,9 @@ __device__ __forceinline__ uint32_t pat_index(uint32_t t, uint32_t r, uint32_t p
   if (r >= 32u) return t;
   return ((t >> r) << (r + 1)) | (par << r) | (t & ((1u << r) - 1u));
 }
+// Pointers that come out of a job record are generic to the compiler (flat loads, which can only be waited for all at once); the tables,
+// scalars and flags live in global memory, and saying so gives global loads with counted waits -- i.e. a prefetch that really overlaps.
+#define ZK_GLOBAL __attribute__((address_space(1)))
 template <bool INL, int AHEAD>
 __device__ __forceinline__ void msmf_accum_body(const FullJob* __restrict__ jobs, uint32_t c, const RecodeK& K, G1X* __restrict__ partial) {
   const FullJob job = jobs[blockIdx.y];
@@ -674,22 +685,61 @@ __device__ __forceinline__ void msmf_accum_body(const FullJob* __restrict__ jobs
   const uint64_t e0 = (uint64_t)t * MSM_CHUNK;
   if (e0 >= items) return;
   const uint64_t e1 = e0 + MSM_CHUNK < items ? e0 + MSM_CHUNK : items;
-  uint32_t pt = (uint32_t)(e0 / job.W), w = (uint32_t)(e0 - (uint64_t)pt * job.W);
+  const uint32_t pt0 = (uint32_t)(e0 / job.W), w0 = (uint32_t)(e0 - (uint64_t)pt0 * job.W);
   const uint32_t half_log = c - 1;
-  // pass 1 (integer work only): the chunk's table offsets; bit 63 = negate, ~0 = nothing to add (digit 0, infinite base)
+  const ZK_GLOBAL G1AE* tab = (const ZK_GLOBAL G1AE*)job.tab;
+  const ZK_GLOBAL Fr* mags = (const ZK_GLOBAL Fr*)job.mags;
+  const ZK_GLOBAL uint8_t* inf = (const ZK_GLOBAL uint8_t*)job.inf;
+  // pass 1 (integer work only): the chunk's table offsets; bit 63 = negate, ~0 = nothing to add (digit 0, infinite base).  A chunk of 16
+  // point-major items touches at most two points when a point has >= 16 windows (every width up to 16 bits): both scalars are requested at
+  // once -- one wait instead of a dependent load + wait per item
   uint64_t offs[MSM_CHUNK];
-  {
-    Recoded rc;
-    uint32_t i = 0;
-    bool live = false, fresh = true;
+  if (job.W >= MSM_CHUNK) {
+    const uint32_t split = job.W - w0;  // items [0, split) belong to point pt0, the rest to pt0 + 1
+    const bool two = e0 + split < e1;
+    const uint32_t iA = pat_index(pt0, job.pat_r, job.pat_par), iB = two ? pat_index(pt0 + 1, job.pat_r, job.pat_par) : iA;
+    const uint8_t fA = inf[iA], fB = inf[iB];
+    Fr mA, mB;
 #pragma unroll
+    for (int l = 0; l < 8; l++) {
+      mA.v[l] = mags[iA].v[l];
+      mB.v[l] = mags[iB].v[l];
+    }
+    const Recoded rA = recode_prepare(mA, K), rB = recode_prepare(mB, K);
+#pragma unroll
+    for (uint32_t s_ = 0; s_ < MSM_CHUNK; s_++) {
+      uint64_t o = ~0ull;
+      if (e0 + s_ < e1) {
+        const bool second = s_ >= split;
+        const uint32_t w = second ? s_ - split : w0 + s_;
+        const uint32_t i = second ? iB : iA;
+        if (!(second ? fB : fA)) {
+          bool nA, nB;
+          const uint32_t dA = recode_digit(rA, c, w, nA), dB = recode_digit(rB, c, w, nB);
+          const uint32_t d = second ? dB : dA;
+          const bool neg = second ? nB : nA;
+          if (d) o = (((((uint64_t)i * job.W + w)) << half_log) + (d - 1)) | (neg ? (1ull << 63) : 0ull);
+        }
+      }
+      offs[s_] = o;
+    }
+  } else {
+    Recoded rc;
+    uint32_t i = 0, pt = pt0, w = w0;
+    bool live = false, fresh = true;
+#pragma unroll 1
     for (uint32_t s_ = 0; s_ < MSM_CHUNK; s_++) {
       uint64_t o = ~0ull;
       if (e0 + s_ < e1) {
         if (fresh) {
           i = pat_index(pt, job.pat_r, job.pat_par);
-          live = !job.inf[i];
-          if (live) rc = recode_prepare(job.mags[i], K);
+          live = !inf[i];
+          if (live) {
+            Fr m;
+#pragma unroll
+            for (int l = 0; l < 8; l++) m.v[l] = mags[i].v[l];
+            rc = recode_prepare(m, K);
+          }
           fresh = false;
         }
         if (live) {
@@ -706,17 +756,27 @@ __device__ __forceinline__ void msmf_accum_body(const FullJob* __restrict__ jobs
       offs[s_] = o;
     }
   }
-  // pass 2: the additions, each table entry requested AHEAD items early (random 96-byte reads from gigabytes: HBM latency, not L2)
+  // pass 2: the additions, each table entry requested AHEAD items early (random one-line reads from gigabytes: HBM latency, not L2)
+  auto fetch = [&](uint64_t o) {
+    G1A r;
+    const ZK_GLOBAL uint32_t* src = (const ZK_GLOBAL uint32_t*)&tab[o & ~(1ull << 63)];
+#pragma unroll
+    for (int l = 0; l < 12; l++) {
+      r.x.v[l] = src[l];
+      r.y.v[l] = src[12 + l];
+    }
+    return r;
+  };
   G1X acc = g1x_zero();
   G1A q[AHEAD];
 #pragma unroll
   for (int a = 0; a < AHEAD; a++)
-    if (a < (int)MSM_CHUNK && offs[a] != ~0ull) q[a] = job.tab[offs[a] & ~(1ull << 63)].p;
+    if (a < (int)MSM_CHUNK && offs[a] != ~0ull) q[a] = fetch(offs[a]);
 #pragma unroll
   for (uint32_t s_ = 0; s_ < MSM_CHUNK; s_++) {
     G1A P = q[s_ % AHEAD];
     const uint64_t o = offs[s_];
-    if (s_ + AHEAD < MSM_CHUNK && offs[s_ + AHEAD] != ~0ull) q[s_ % AHEAD] = job.tab[offs[s_ + AHEAD] & ~(1ull << 63)].p;
+    if (s_ + AHEAD < MSM_CHUNK && offs[s_ + AHEAD] != ~0ull) q[s_ % AHEAD] = fetch(offs[s_ + AHEAD]);
     if (o != ~0ull) {
       if (o >> 63) P.y = fp_neg(P.y);
       acc = g1x_madd<INL>(acc, fq_unpack(P.x), fq_unpack(P.y));
