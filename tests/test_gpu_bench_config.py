@@ -127,3 +127,41 @@ def test_oracle_matches_the_benchmarked_configuration_at_batch_256(zk, wl):
     fr2[0, 0] ^= 1
     _, bad = bench.cpu_baseline_check_only(zk, wl, [("fc", len(wl.shapes) - 1)], (wl.challenges(9), fr2, aff, inf))
     assert not bad["ok"] and bad["mismatch"] == ["zkFC7"]
+
+
+def test_pending_g1_batches_survive_reset_destroy_and_flag_changes(zk):
+    """g1_batch > 1 leaves a sealed proof's G1 phase with the context until partners arrive.  Whoever touches such a transcript (read, reset,
+    destroy), changes the batch size, or synchronises the context must get the same values as an unbatched proof -- and nothing may dangle."""
+    import bench
+    from zkdl_amd.capi import Transcript
+    wl = bench.Workload(zk, [64, 96, 48, 32], 16, seed=3, inflight=4)
+    want = []
+    tr = Transcript(zk)
+    for st in range(3):
+        wl.prove(wl.challenges(st), tr)
+        want.append((tr.read()[0], tr.read_affine()))
+    zk.set_flag("g1_batch", 3)
+    try:
+        # (a) one pending proof, read at once: runs alone
+        wl.prove(wl.challenges(0), wl.trs[0]); wl.trs[0].seal()
+        fr, _ = wl.trs[0].read()
+        assert eq(fr, want[0][0]) and eq(wl.trs[0].read_affine()[0], want[0][1][0])
+        # (b) two pending, the batch size changes under them: the flag change flushes them
+        wl.prove(wl.challenges(1), wl.trs[1]); wl.trs[1].seal()
+        wl.prove(wl.challenges(2), wl.trs[2]); wl.trs[2].seal()
+        zk.set_flag("g1_batch", 2)
+        assert eq(wl.trs[1].read()[0], want[1][0]) and eq(wl.trs[2].read_affine()[0], want[2][1][0])
+        # (c) a pending transcript is destroyed, another one reset, then the context synchronised; a fresh proof afterwards is still right
+        t_a, t_b = Transcript(zk), Transcript(zk)
+        wl.prove(wl.challenges(0), t_a); t_a.seal()
+        t_a.close()
+        wl.prove(wl.challenges(1), t_b); t_b.seal()
+        t_b.reset()
+        zk.sync()
+        wl.prove(wl.challenges(2), t_b); t_b.seal()
+        zk.sync()
+        assert eq(t_b.read()[0], want[2][0]) and eq(t_b.read_affine()[0], want[2][1][0])
+        t_b.close()
+    finally:
+        zk.set_flag("g1_batch", 1)
+    tr.close()
