@@ -140,8 +140,14 @@ int zk_ctx_create(int device, zk_ctx** out) {
     if (nl < 0) nl = 0;
     if (nl > 16) nl = 16;
     ctx->lanes.resize((size_t)nl);
+    // ZKDL_LANE_PRIO (experiment): 1 = worker lanes at the highest stream priority (their launches are small and latency-bound; the G1 stream carries the bulk)
+    int lane_prio = 0;
+    if (const char* e = getenv("ZKDL_LANE_PRIO")) lane_prio = atoi(e);
+    int lp_least = 0, lp_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lp_least, &lp_greatest);
     for (auto& l : ctx->lanes)
-      if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&l.done, hipEventDisableTiming) != hipSuccess) {
+      if ((lane_prio ? hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, lane_prio > 0 ? lp_greatest : lp_least) : hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking)) != hipSuccess ||
+          hipEventCreateWithFlags(&l.done, hipEventDisableTiming) != hipSuccess) {
         ctx->lanes.clear();  // no lanes: everything stays on the main stream
         break;
       }
@@ -242,7 +248,16 @@ int zk_ctx_destroy(zk_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)ctx->flush_g1_pending();
   ctx->join_all();
-  (void)hipDeviceSynchronize();
+  // drain the streams this context owns, one by one.  (Not hipDeviceSynchronize: the device may be shared with other contexts or with torch -- and
+  // a device-wide synchronise at this point was observed to hang after long test sessions where the per-stream ones return at once.)
+  (void)hipStreamSynchronize(ctx->main_stream);
+  for (auto& l : ctx->lanes)
+    if (l.stream) (void)hipStreamSynchronize(l.stream);
+  for (auto& g : ctx->g1_lanes)
+    if (g.stream) (void)hipStreamSynchronize(g.stream);
+  for (auto& g : ctx->tail_lanes)
+    if (g.stream) (void)hipStreamSynchronize(g.stream);
+  if (ctx->g1_full.stream) (void)hipStreamSynchronize(ctx->g1_full.stream);
   ctx->prof_flush();
   for (auto& l : ctx->lanes) {
     if (l.stream) (void)hipStreamDestroy(l.stream);
