@@ -414,7 +414,7 @@ def main():
     ap.add_argument("--no-msm-probe", action="store_true", help="skip the full-width 2^24-pair zk_msm_batch throughput probe")
     ap.add_argument("--spinup-ms", type=float, default=400.0, help="untimed proofs before the W warm-up steps until this much wall time has passed: the first process on a "
                     "fresh box otherwise runs its first ~100 ms 12 %% slow (GPU power state); 0 disables")
-    ap.add_argument("--prof-steps", type=int, default=2, help="proofs per event-profiled pass after the timed region (ZKDL_PROF_TRACE=<file> writes their per-launch timeline)")
+    ap.add_argument("--prof-steps", type=int, default=3, help="proofs per event-profiled pass after the timed region (ZKDL_PROF_TRACE=<file> writes their per-launch timeline)")
     ap.add_argument("--drain", type=int, default=-1, help="the last N proofs of a run take the short G1 form (every round commitment an MSM instead of derived): "
                     "they have no later proofs to hide the longer derived form under")
     ap.add_argument("--pair", type=int, default=1, choices=[1, 2], help="proofs submitted together (zk_transcript_seal_pair): 2 = the Fr phases of two consecutive "
@@ -846,6 +846,21 @@ def main():
                 hit = rec if hit is None or rec.get("launches", 0) > hit.get("launches", 0) else hit
         return hit
 
+    # Device time per proof in the TIMED configuration.  The standalone pass runs every proof's G1 phase by itself; the timed region runs g1_batch
+    # proofs' phases as one batch, where the launches that are one dependent chain on a handful of waves (derived round commitments, canonical form)
+    # take as long for three proofs as for one.  Their launch count per proof is taken from the concurrent pass (the timed region's schedule, nprof a
+    # multiple of g1_batch) and priced at the standalone launch duration; every other family does work proportional to the proofs in it.
+    shared_chain = ("msm_derive", "g1_canonicalise")
+
+    def timed_launches(k):
+        return (prof_conc[k]["launches"] / nprof) if k in prof_conc else prof[k]["launches"] / nprof
+
+    def timed_ms(k):
+        per_step = prof[k]["ms"] / nprof
+        if k in shared_chain and k in prof_conc and prof[k]["launches"]:
+            return per_step * min(1.0, prof_conc[k]["launches"] / prof[k]["launches"])
+        return per_step
+
     def roofline_of(k):
         pv = prof[k]
         launches = max(pv["launches"], 1)
@@ -858,6 +873,7 @@ def main():
         return {"kernel": k, "bound": "valu", "achieved": ach, "peak": VALU_PEAK_TMACPS, "unit": "TMAC/s (32x32->64 integer multiply-accumulates per second)",
                 "frac": ach / VALU_PEAK_TMACPS, "traffic": traffic, "avg_launch_ms": avg_ms, "alg_macs_per_launch": macs_launch, "ms_per_step": pv["ms"] / nprof,
                 "launches_per_step": pv["launches"] // nprof,
+                "timed_region_launches_per_step": timed_launches(k), "timed_region_ms_per_step": timed_ms(k),
                 "concurrent_avg_launch_ms": (prof_conc[k]["ms"] / max(prof_conc[k]["launches"], 1)) if k in prof_conc else None,
                 "hbm": {"achieved": hbm_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_ach / HBM_PEAK_GBPS, "alg_bytes_per_launch": pv["bytes"] / launches,
                         "traffic_bytes_per_launch": traffic},
@@ -870,13 +886,15 @@ def main():
         kernels[r_["kernel"]]["alg_TMACps"] = r_["achieved"]
         kernels[r_["kernel"]]["valu_frac"] = r_["frac"]
     if modelled:
-        dom = max(modelled, key=lambda k: kernels[k]["ms_per_step"])
+        dom = max(modelled, key=timed_ms)
         roofline = dict(roofline_of(dom))
         # chip-filling: launches of at least ~4 waves per SIMD's worth of workgroups; on this path that is the accumulation and the big rounds
         filling = [k for k in modelled if k in ("msm_table_accum", "msm_accum", "sumcheck_bin_round", "sumcheck_hp_round", "binp_words", "fr_contract")]
         fill = max(filling, key=lambda k: kernels[k]["ms_per_step"]) if filling else dom
         roofline["measured"] = "standalone launches (worker streams off) after the timed region, HIP events on the launching stream; rocprofv3 of `bench.py --serial` agrees (profiles/)"
-        roofline["selection"] = "the family with the most device time per proof among all families with a MAC model (roofline_all); roofline_chip_filling = the longest family whose launches fill the chip"
+        roofline["selection"] = ("the family with the most device time per proof IN THE TIMED CONFIGURATION (timed_region_ms_per_step: standalone launch duration x launches per proof "
+                                 "of the timed schedule, where g1_batch proofs share the launches of the derived-commitment and canonical-form chains) among all families with a "
+                                 "MAC model (roofline_all lists every one, with ms_per_step of an unbatched proof beside it); roofline_chip_filling = the longest family whose launches fill the chip")
         roofline["note"] = ("wide-integer modular arithmetic: no MFMA mapping; HBM traffic (PMC) is at or below the algorithmic bytes (window tables hit L2), the SIMDs are "
                             "instruction-issue bound; peak = measured issue rate of the MAC instruction, so frac is the share of issue slots doing algorithmic MACs. "
                             "Families that run on a handful of waves (msm_derive, g1_canonicalise, msm_horner: dependent chains of field products) are latency-bound: "
