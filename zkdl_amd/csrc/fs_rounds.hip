@@ -92,6 +92,7 @@ __device__ __forceinline__ void k_fs_round(uint32_t zk_nblk, const Fr* __restric
       a_cur[e0] = a0;
       if (e1 < cur_size) a_cur[e1] = a1;
     }
+    if (MODE == FSC_BIN && l_is_zero(a0) && l_is_zero(a1)) continue;  // nothing to add (bit tables are mostly zero in their high positions)
     const Fr da = fr_sub(a1, a0);
     Fr c0, c1, c2;
     if (MODE == FSC_BIN) {
@@ -401,7 +402,8 @@ static int relu_prove_fs_body(zk_ctx* ctx, const zk_relu* relu, const Fr* x, uin
   if ((uint64_t)n * 32 > 0xffffffffull) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   const uint32_t k = ceil_log2(n);
   const size_t add_fr = 3 * (k + 5) + 1 + 32 + 3 * (k + 4) + 1 + 16 + 3 * k + 2;
-  ZK_TRY(relu_materialise_bins(ctx, const_cast<zk_relu*>(relu)));  // before recording starts
+  const bool packed = ctx->relu_packed && relu->mag_packed && relu->rem_packed;
+  if (!packed) ZK_TRY(relu_materialise_bins(ctx, const_cast<zk_relu*>(relu)));  // before recording starts
   ZK_TRY(tr->ensure(add_fr, 0));
   Fr* out = tr->fr_d + tr->n_fr;
   tr->n_fr += add_fr;
@@ -425,15 +427,27 @@ static int relu_prove_fs_body(zk_ctx* ctx, const zk_relu* relu, const Fr* x, uin
   ZK_TRY(upload_fr(ctx, chd, ch.data(), (uint32_t)ch.size()));
   Fr* c = chd.get();
   FsState* states = reinterpret_cast<FsState*>(c + tot);
-  ZK_TRY(run_sumcheck_fs<FSC_BIN>(ctx, relu->mag_bin, nullptr, n * 32, states + 0, c + offs[1], c + offs[0], k + 5, out));
-  out += 3 * (k + 5) + 1;
-  ZK_TRY(fr_partial_me_dev(ctx, relu->mag_bin, n * 32, c + offs[4], k, 32, out));
-  out += 32;
-  rec_split(ctx, REC_GROUP_RELU_REM);
-  ZK_TRY(run_sumcheck_fs<FSC_BIN>(ctx, relu->rem_bin, nullptr, n * 16, states + 1, c + offs[3], c + offs[2], k + 4, out));
-  out += 3 * (k + 4) + 1;
-  ZK_TRY(fr_partial_me_dev(ctx, relu->rem_bin, n * 16, c + offs[4], k, 16, out));
-  out += 16;
+  DBuf<Fr> t3_mag, t3_rem;  // declared behind the lane scope: released into the recording's deferred frees
+  if (packed) {
+    // rounds 0..2 from the packed words (one weighted byte histogram, taken before any challenge exists), the rest on the table V3[byte]
+    ZK_TRY(fsb_sumcheck_head_dev(ctx, relu->mag_packed, n, 32, c + offs[0], k + 5, states + 0, c + offs[1], out, c + offs[4], out + 3 * (k + 5) + 1, t3_mag));
+    ZK_TRY(run_sumcheck_fs<FSC_BIN>(ctx, t3_mag.get(), nullptr, n * 4, states + 0, c + offs[1] + 3, c + offs[0] + 3, k + 2, out + 9));
+    out += 3 * (k + 5) + 1 + 32;
+    rec_split(ctx, REC_GROUP_RELU_REM);
+    ZK_TRY(fsb_sumcheck_head_dev(ctx, relu->rem_packed, n, 16, c + offs[2], k + 4, states + 1, c + offs[3], out, c + offs[4], out + 3 * (k + 4) + 1, t3_rem));
+    ZK_TRY(run_sumcheck_fs<FSC_BIN>(ctx, t3_rem.get(), nullptr, n * 2, states + 1, c + offs[3] + 3, c + offs[2] + 3, k + 1, out + 9));
+    out += 3 * (k + 4) + 1 + 16;
+  } else {
+    ZK_TRY(run_sumcheck_fs<FSC_BIN>(ctx, relu->mag_bin, nullptr, n * 32, states + 0, c + offs[1], c + offs[0], k + 5, out));
+    out += 3 * (k + 5) + 1;
+    ZK_TRY(fr_partial_me_dev(ctx, relu->mag_bin, n * 32, c + offs[4], k, 32, out));
+    out += 32;
+    rec_split(ctx, REC_GROUP_RELU_REM);
+    ZK_TRY(run_sumcheck_fs<FSC_BIN>(ctx, relu->rem_bin, nullptr, n * 16, states + 1, c + offs[3], c + offs[2], k + 4, out));
+    out += 3 * (k + 4) + 1;
+    ZK_TRY(fr_partial_me_dev(ctx, relu->rem_bin, n * 16, c + offs[4], k, 16, out));
+    out += 16;
+  }
   rec_split(ctx, REC_GROUP_FC_OPEN);
   if (k > 0 && n <= (1u << (k - 1))) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions 3");
   ZK_TRY(run_sumcheck_fs<FSC_HP>(ctx, x, relu->sign, n, states + 2, c + offs[6], c + offs[5], k, out));

@@ -22,6 +22,7 @@
 #include "layers.hpp"
 
 #include "dev_util.hpp"
+#include "sha256.hpp"
 
 namespace zk {
 
@@ -718,6 +719,233 @@ int binp_sumcheck_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb, 
   ZK_LAUNCHB(ctx, "binp_finish", 32ull * 7 * grid, 256, k_binp_finish, dim3(1), 0, (const Fr*)partial.get(), grid, proof_d);
   // rounds 3 .. k-1 and the final a(0): generic path on the 8x smaller table
   return sumcheck_bin_dev(ctx, a3.get(), a3n, u_d + 3, v_d + 3, k - 3, proof_d + 9);
+}
+
+// ====================================================================================================
+// Sound mode (fs_rounds.hip): the in-word rounds 0..2 of a bit sumcheck when round r's fold challenge is a hash of the messages of
+// rounds < r.  The weighted byte histogram H[p][e] = sum_{g : byte_p(g) = e} eq(u[log nb:], g) does not depend on any fold
+// challenge, so it is taken ONCE, before the first round; each round's three coefficient sums are then  sum_bins f_r[bin] * H[bin]
+// with factors that need only x_0 .. x_{r-1} (binb_factors' rounds 0..2) -- one workgroup computes the three messages one after the
+// other, hashing between them, and leaves x_0..x_2, the table V3[byte] (a byte's eight bits folded by them) and, from the second
+// histogram H2 (weights eq(u_rec, g)), the partial_me that follows the sumcheck.  Rounds >= 3 run on the table V3[byte_i]
+// (one entry per byte: 8x smaller than the one-element-per-bit tensor the first sound-mode prover streamed).
+template <int NB, class WordT>
+__device__ __forceinline__ void k_fsb_hist(uint32_t zk_nblk, const WordT* __restrict__ packed, uint32_t n, const Fr* __restrict__ AH, const Fr* __restrict__ BH, uint32_t ch,
+                                                   const Fr* __restrict__ A2, const Fr* __restrict__ B2, uint32_t c2, unsigned long long* __restrict__ slabs) {
+  constexpr uint32_t NPOS = NB / 8, NH = NPOS * 256, NBINS = 2 * NH;
+  extern __shared__ unsigned long long lds64[];
+  unsigned long long* H = lds64;
+  for (uint32_t i = threadIdx.x; i < NBINS * BINB_LIMBS_LDS; i += blockDim.x) H[i] = 0ull;
+  __syncthreads();
+  const uint32_t mh = (1u << ch) - 1u, m2 = (1u << c2) - 1u;
+  const uint32_t per = (n + zk_nblk - 1) / zk_nblk;   // <= BINB_WORDS_PER_WG (host): no counter overflows
+  const uint32_t g_end = min(n, (blockIdx.x + 1) * per);
+  for (uint32_t g = blockIdx.x * per + threadIdx.x; g < g_end; g += blockDim.x) {
+    const uint32_t word = packed[g];
+    if (word == 0u) continue;
+    unsigned long long l[5], l2[5];
+    binb_limbs51(fr_mul(AH[g & mh], BH[g >> ch]), l);
+    binb_limbs51(fr_mul(A2[g & m2], B2[g >> c2]), l2);
+#pragma unroll
+    for (uint32_t p = 0; p < NPOS; p++) {
+      const uint32_t b = (word >> (8 * p)) & 255u;
+      if (b) {
+        unsigned long long* bin = H + (p * 256 + b) * BINB_LIMBS_LDS;
+        unsigned long long* bin2 = bin + NH * BINB_LIMBS_LDS;
+#pragma unroll
+        for (int j = 0; j < 5; j++) atomicAdd(bin + j, l[j]);
+#pragma unroll
+        for (int j = 0; j < 5; j++) atomicAdd(bin2 + j, l2[j]);
+      }
+    }
+  }
+  __syncthreads();
+  unsigned long long* dst = slabs + (size_t)blockIdx.x * NBINS * BINB_LIMBS_LDS;
+  for (uint32_t i = threadIdx.x; i < NBINS * BINB_LIMBS_LDS; i += blockDim.x) dst[i] = H[i];
+}
+
+// One workgroup of 1024 lanes, one histogram bin (p, e) per lane.  proof[0..9): the messages of rounds 0..2; fold[0..3): x_0..x_2;
+// v3tab[256]; pme_out[nb]; *state advanced by three rounds.
+__device__ __forceinline__ void k_fsb_rounds(uint32_t zk_nblk, const unsigned long long* __restrict__ sums, BytesLayout L, const Fr* __restrict__ u, Fr* __restrict__ fold,
+                                                     FsState* __restrict__ state, Fr* __restrict__ proof, Fr* __restrict__ pme_out, Fr* __restrict__ v3tab) {
+  __shared__ Fr red[48];
+  __shared__ Fr elo[28];
+  __shared__ Fr xs[3];
+  __shared__ Fr eqv[8];
+  const uint32_t tid = threadIdx.x;
+  if (tid < 28) {  // position weights of the three rounds: Elo_0[16] | Elo_1[8] | Elo_2[4]  (k_binb_prep)
+    Fr r;
+    if (tid < 16) r = tid < L.npos * 4 ? eq_prod(u + 1, L.lognb - 1, tid) : fr_zero();
+    else if (tid < 24) r = (tid - 16) < L.npos * 2 ? eq_prod(u + 2, L.lognb - 2, tid - 16) : fr_zero();
+    else r = (tid - 24) < L.npos ? eq_prod(u + 3, L.lognb - 3, tid - 24) : fr_zero();
+    elo[tid] = r;
+  }
+  const bool own = tid < L.nH;  // nH <= blockDim.x = 1024
+  const uint32_t p = tid >> 8, e = tid & 255u;
+  Fr h = fr_zero();
+  if (own) h = binb_bin_to_fr(sums + (size_t)tid * BINB_LIMBS_LDS * 2);
+  const bool live = own && !l_is_zero(h);
+  FsState st;
+  if (tid == 0) st = *state;
+  __syncthreads();
+  const Fr zero = fr_zero(), one = fr_one();
+  auto send = [&](uint32_t r, const Fr& c0, const Fr& p1, const Fr& c2) {  // lane 0: the round's message, then the hash step
+    const Fr c1 = fr_sub(fr_sub(p1, c0), c2);
+    proof[3 * r + 0] = c0;
+    proof[3 * r + 1] = c1;
+    proof[3 * r + 2] = c2;
+    const Fr x = fs_round_step(st, c0, c1, c2);
+    fold[r] = x;
+    xs[r] = x;
+  };
+  {  // round 0: a pair is two bits: c0 = 0, c2 = sum of the weights of the pairs that differ, c1 = -c2
+    Fr a = zero, z1 = zero, z2 = zero;
+    if (live) {
+      const uint32_t x = e ^ (e >> 1);
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++)
+        if ((x >> (2 * i)) & 1u) a = fr_add(a, elo[4 * p + i]);
+      a = fr_mul(a, h);
+    }
+    block_sum3_fr(a, z1, z2, red);
+    if (tid == 0) send(0, zero, zero, a);
+  }
+  __syncthreads();
+  const Fr v0 = xs[0], nv0 = fr_sub(one, v0);
+  {  // round 1: a pair is two bit pairs, each folded by x_0
+    Fr c0 = zero, p1 = zero, c2 = zero;
+    if (live) {
+      for (uint32_t i = 0; i < 2; i++) {
+        const uint32_t nib = (e >> (4 * i)) & 15u;
+        if (!nib) continue;
+        auto fold1 = [&](uint32_t bits) { return bits == 0 ? zero : bits == 1 ? nv0 : bits == 2 ? v0 : one; };
+        const Fr a0 = fold1(nib & 3u), a1 = fold1(nib >> 2), w = elo[16 + 2 * p + i], d = fr_sub(a1, a0);
+        c0 = fr_add(c0, fr_mul(w, fr_sub(fr_sqr(a0), a0)));
+        p1 = fr_add(p1, fr_mul(w, fr_sub(fr_sqr(a1), a1)));
+        c2 = fr_add(c2, fr_mul(w, fr_sqr(d)));
+      }
+      c0 = fr_mul(c0, h);
+      p1 = fr_mul(p1, h);
+      c2 = fr_mul(c2, h);
+    }
+    block_sum3_fr(c0, p1, c2, red);
+    if (tid == 0) send(1, c0, p1, c2);
+  }
+  __syncthreads();
+  const Fr v1 = xs[1], nv1 = fr_sub(one, v1);
+  const Fr e4[4] = {fr_mul(nv0, nv1), fr_mul(v0, nv1), fr_mul(nv0, v1), fr_mul(v0, v1)};
+  {  // round 2: a pair is the byte's two nibbles, each folded by (x_0, x_1)
+    Fr c0 = zero, p1 = zero, c2 = zero;
+    if (live) {
+      Fr lo4 = zero, hi4 = zero;
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) {
+        if ((e >> i) & 1u) lo4 = fr_add(lo4, e4[i]);
+        if ((e >> (4 + i)) & 1u) hi4 = fr_add(hi4, e4[i]);
+      }
+      const Fr w = fr_mul(elo[24 + p], h), d = fr_sub(hi4, lo4);
+      c0 = fr_mul(w, fr_sub(fr_sqr(lo4), lo4));
+      p1 = fr_mul(w, fr_sub(fr_sqr(hi4), hi4));
+      c2 = fr_mul(w, fr_sqr(d));
+    }
+    block_sum3_fr(c0, p1, c2, red);
+    if (tid == 0) {
+      send(2, c0, p1, c2);
+      *state = st;
+    }
+  }
+  __syncthreads();
+  if (tid < 8) {
+    const Fr v2 = xs[2];
+    eqv[tid] = fr_mul(e4[tid & 3u], (tid & 4u) ? v2 : fr_sub(one, v2));
+  }
+  __syncthreads();
+  if (tid < 256) {
+    Fr t = zero;
+#pragma unroll
+    for (uint32_t i = 0; i < 8; i++)
+      if ((tid >> i) & 1u) t = fr_add(t, eqv[i]);
+    v3tab[tid] = t;
+  }
+  // partial_me(u_rec, nb) from H2: as in k_binb_finish
+  Fr h2 = fr_zero();
+  if (own) h2 = binb_bin_to_fr(sums + (size_t)(L.nH + tid) * BINB_LIMBS_LDS * 2);
+  const uint32_t wave = tid >> 6, lane = tid & 63u;
+  for (uint32_t j = 0; j < 8; j++) {
+    Fr x = ((tid >> j) & 1u) ? h2 : fr_zero();
+    x = wave_sum_fr(x);
+    __syncthreads();
+    if (lane == 0) red[wave] = x;
+    __syncthreads();
+    if (lane == 0 && (wave & 3u) == 0 && tid < L.nH) pme_out[8 * (tid >> 8) + j] = fr_add(fr_add(red[wave], red[wave + 1]), fr_add(red[wave + 2], red[wave + 3]));
+  }
+}
+
+// out[i] = V3[byte i]: the table of round 3
+__device__ __forceinline__ void k_fsb_expand(uint32_t zk_nblk, const uint8_t* __restrict__ bytes, uint32_t n3, const Fr* __restrict__ v3tab, Fr* __restrict__ out) {
+  __shared__ Fr V3[256];
+  for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) V3[i] = v3tab[i];
+  __syncthreads();
+  // four consecutive bytes per lane and step (one 32-bit load)
+  const uint32_t n4 = n3 / 4;
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += zk_nblk * blockDim.x) {
+    const uint32_t w = reinterpret_cast<const uint32_t*>(bytes)[q];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) {
+      const uint32_t b = (w >> (8 * j)) & 255u;
+      out[4 * (size_t)q + j] = b ? V3[b] : fr_zero();
+    }
+  }
+  if (blockIdx.x == 0) {
+    for (uint32_t i = 4 * n4 + threadIdx.x; i < n3; i += blockDim.x) out[i] = V3[bytes[i]];
+  }
+}
+
+// rounds 0..2 (messages into proof_d[0..9), x_0..x_2 into fold_d[0..3), *state_d advanced), partial_me(u_rec, nb) into pme_d, and the
+// table of round 3 (n * nb / 8 entries) into t3
+int fsb_sumcheck_head_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb, const Fr* u_d, uint32_t k, void* state_d, Fr* fold_d, Fr* proof_d, const Fr* u_rec_d, Fr* pme_d,
+                          DBuf<Fr>& t3) {
+  if (nb != 32 && nb != 16) return ctx->fail(ZK_ERR_ARG, "packed sumcheck: nb must be 16 or 32");
+  const BytesLayout L = bytes_layout(nb);
+  if (n == 0 || k != ceil_log2(n) + L.lognb) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
+  const uint32_t kh = k - L.lognb;
+  const uint32_t ch = kh < 10 ? kh : 10;
+  const uint32_t nbins = 2 * L.nH, ncount = nbins * BINB_LIMBS_LDS;
+  ZK_ALLOC(ctx, AH, Fr, (size_t)1 << ch);
+  ZK_ALLOC(ctx, BH, Fr, (size_t)1 << (kh - ch));
+  ZK_ALLOC(ctx, A2, Fr, (size_t)1 << ch);
+  ZK_ALLOC(ctx, B2, Fr, (size_t)1 << (kh - ch));
+  const uint32_t nt = (1u << ch) + (1u << (kh - ch));
+  ZK_LAUNCHB(ctx, "binp_prep", 32ull * nt, 256, k_eq_pair_tables, dim3(stream_grid(nt, 256, 16)), 0, u_d + L.lognb, kh, ch, AH.get(), BH.get());
+  ZK_LAUNCHB(ctx, "binp_prep", 32ull * nt, 256, k_eq_pair_tables, dim3(stream_grid(nt, 256, 16)), 0, u_rec_d, kh, ch, A2.get(), B2.get());
+  const uint32_t grid = (n + BINB_WORDS_PER_WG - 1) / BINB_WORDS_PER_WG;
+  ZK_ALLOC(ctx, slabs, unsigned long long, (size_t)grid * ncount);
+  ZK_ALLOC(ctx, sums, unsigned long long, (size_t)ncount * 2);
+  ZK_ALLOC(ctx, v3tab, Fr, 256);
+  const size_t lds = (size_t)ncount * 8;
+  const uint64_t bytes = (uint64_t)n * (nb / 8);
+  if (nb == 32) {
+    if (ctx->lds_first_use(zk::Kern<1024, &k_fsb_hist<32, uint32_t>>::desc())) {
+      zk::Kern<1024, &k_fsb_hist<32, uint32_t>>::set_max_lds(lds);
+      (void)hipGetLastError();
+    }
+    ZK_LAUNCHB(ctx, "fs_bit_hist", bytes, 1024, (k_fsb_hist<32, uint32_t>), dim3(grid), lds, (const uint32_t*)packed, n, (const Fr*)AH.get(), (const Fr*)BH.get(), ch, (const Fr*)A2.get(),
+              (const Fr*)B2.get(), ch, slabs.get());
+  } else {
+    if (ctx->lds_first_use(zk::Kern<1024, &k_fsb_hist<16, uint16_t>>::desc())) {
+      zk::Kern<1024, &k_fsb_hist<16, uint16_t>>::set_max_lds(lds);
+      (void)hipGetLastError();
+    }
+    ZK_LAUNCHB(ctx, "fs_bit_hist", bytes, 1024, (k_fsb_hist<16, uint16_t>), dim3(grid), lds, (const uint16_t*)packed, n, (const Fr*)AH.get(), (const Fr*)BH.get(), ch, (const Fr*)A2.get(),
+              (const Fr*)B2.get(), ch, slabs.get());
+  }
+  ZK_LAUNCHB(ctx, "binp_finish", 8ull * grid * ncount, 256, k_binb_reduce, dim3(stream_grid(ncount, 256, 32)), 0, (const unsigned long long*)slabs.get(), grid, ncount, sums.get());
+  ZK_LAUNCHB(ctx, "fs_bit_rounds", 16ull * ncount, 1024, k_fsb_rounds, dim3(1), 0, (const unsigned long long*)sums.get(), L, u_d, fold_d, reinterpret_cast<FsState*>(state_d), proof_d, pme_d,
+            v3tab.get());
+  const uint32_t n3 = n * (nb / 8);
+  if (!t3.alloc(ctx, n3)) return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: sumcheck tables");
+  ZK_LAUNCHB(ctx, "fs_bit_expand", (uint64_t)n3 + 32ull * n3, 256, k_fsb_expand, dim3(stream_grid((n3 + 3) / 4, 256, 2048)), 0, (const uint8_t*)packed, n3, (const Fr*)v3tab.get(), t3.get());
+  return ZK_OK;
 }
 
 // FrTensor::partial_me(u, nb) of the bit tensor: nb outputs
