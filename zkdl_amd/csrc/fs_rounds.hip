@@ -16,8 +16,10 @@
 //     leaves x_r in device memory for the next launch.  No host round trip: a sumcheck is still one asynchronous chain, and the
 //     chains of different layers are still zipped by the recorder.
 //   * the last <= 10 rounds run in one workgroup with the table in LDS (k_fs_tail), one lane hashing between rounds.
-//   * the bit sumchecks of zkReLU run on the one-field-element-per-bit tensors (the byte-histogram form takes rounds 0-4 in one
-//     pass, which presumes their challenges).
+//   * the bit sumchecks of zkReLU take their rounds 0-2 from ONE weighted byte histogram of the packed words -- it depends on the weight
+//     point only, which is statement-derived -- turned into the three messages by one workgroup that hashes between them
+//     (relu_packed.hip: fsb_sumcheck_head_dev); rounds >= 3 run here on the table V3[byte].  (The throughput mode's five-round pass
+//     presumes x_3 and x_4 before their rounds.)
 //   * the opening's point is u_out || u_in and u_in are the inner-product sumcheck's round challenges, so the opening is recorded
 //     BEHIND the sumcheck in the same chain; its own folding uses the point's coordinates (commitment.cu:43-81), no new coins.
 // Challenges that are evaluation points fixed before a sub-protocol starts (u_bs, u_out, u_z, u_r, u_rec, u_hp) stay
