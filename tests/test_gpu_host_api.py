@@ -20,42 +20,14 @@ def test_cpp_class_api():
     assert "host api ok" in out.stdout
 
 
-def test_demo_driver_matches_float_model_and_oracle(tmp_path, oracle):
-    """model.py -> ./demo: demo.out (Y_hat, un-Montgomery'd, padded) equals the oracle's quantised
-    forward bit for bit and de-quantises to the float network's output (SURVEY App. E)."""
-    exe = os.path.join(HOST, "demo")
-    if not os.path.exists(exe):
-        pytest.skip("zkdl_amd/host/demo not built (needs LibTorch)")
+def _oracle_replay_matches(d, dims, batch, oracle):
+    """Replay the demo's generators and challenges (--dump) through the oracle and compare the serialised transcript -- every Fr value
+    bit for bit, every G1 value in affine-canonical form."""
     import torch
-    import bigint_model as bm
-    d = str(tmp_path)
-    subprocess.run([sys.executable, "-m", "zkdl_amd.model", "--dims", "6,5,4", "--batch", "3", "--seed", "7", "--out-dir", d], check=True, cwd=ROOT)
-    run = subprocess.run([exe, os.path.join(d, "traced_model.pt"), os.path.join(d, "sample_input.pt"), "--seed", "5", "--dump", d], capture_output=True, text=True, cwd=d, timeout=600)
-    assert run.returncode == 0, run.stdout + run.stderr
-    assert "Total number of parameters: 50" in run.stdout and "seconds per data point." in run.stdout
-    lines = open(os.path.join(d, "demo.out")).read().strip().strip("[]").split("\n")
-    vals = [int(x, 16) for x in lines]
-    assert len(vals) == 4 * 4                                    # B_p x out_p
+    from mlp_util import ceil_log2, layer_shapes, prove_mlp_oracle
     m = torch.jit.load(os.path.join(d, "traced_model.pt"))
     W = [p.detach().numpy().T.copy() for p in m.parameters()]    # [in, out]
     x = list(torch.jit.load(os.path.join(d, "sample_input.pt")).parameters())[0].detach().numpy()
-    want = np.maximum(x.astype(np.float64) @ W[0], 0) @ W[1]
-    for b in range(3):
-        for o in range(4):
-            v = vals[b * 4 + o]
-            v = v - bm.R_MOD if v > bm.R_MOD // 2 else v
-            assert abs(v / 2.0 ** 32 - want[b, o]) < 2e-3
-    # bit-exact against the oracle's quantised forward
-    Wq = [oracle.fr_mont(oracle.float_to_fr(W[0], 8, 8)), oracle.fr_mont(oracle.float_to_fr(W[1], 8, 4))]
-    X = oracle.fr_mont(oracle.float_to_fr(x, 4, 8))
-    A, *_ = oracle.relu_forward(oracle.fc_forward(X, Wq[0], 4, 8, 8))
-    Y = oracle.fr_unmont(oracle.fc_forward(A, Wq[1], 4, 8, 4))
-    assert vals == [bm.limbs_to_int(r) for r in Y]
-
-    # the proof itself: replay the demo's generators and challenges (--dump) through the oracle and compare the
-    # serialised transcript -- every Fr value bit for bit, every G1 value in affine-canonical form
-    from mlp_util import ceil_log2, layer_shapes, prove_mlp_oracle
-    dims, batch = [6, 5, 4], 3
     shapes = layer_shapes(dims)
     gens = [np.fromfile(os.path.join(d, "gens_%d.bin" % i), dtype=np.uint32).reshape(-1, 36) for i in range(len(shapes))]
     assert [g.shape[0] for g in gens] == [s["n_gens"] for s in shapes]
@@ -98,6 +70,42 @@ def test_demo_driver_matches_float_model_and_oracle(tmp_path, oracle):
     assert np.array_equal(inf_d, inf_o) and np.array_equal(aff_d, aff_o)
 
 
+def test_demo_driver_matches_float_model_and_oracle(tmp_path, oracle):
+    """model.py -> ./demo: demo.out (Y_hat, un-Montgomery'd, padded) equals the oracle's quantised
+    forward bit for bit and de-quantises to the float network's output (SURVEY App. E)."""
+    exe = os.path.join(HOST, "demo")
+    if not os.path.exists(exe):
+        pytest.skip("zkdl_amd/host/demo not built (needs LibTorch)")
+    import torch
+    import bigint_model as bm
+    d = str(tmp_path)
+    subprocess.run([sys.executable, "-m", "zkdl_amd.model", "--dims", "6,5,4", "--batch", "3", "--seed", "7", "--out-dir", d], check=True, cwd=ROOT)
+    run = subprocess.run([exe, os.path.join(d, "traced_model.pt"), os.path.join(d, "sample_input.pt"), "--seed", "5", "--dump", d], capture_output=True, text=True, cwd=d, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "Total number of parameters: 50" in run.stdout and "seconds per data point." in run.stdout
+    lines = open(os.path.join(d, "demo.out")).read().strip().strip("[]").split("\n")
+    vals = [int(x, 16) for x in lines]
+    assert len(vals) == 4 * 4                                    # B_p x out_p
+    m = torch.jit.load(os.path.join(d, "traced_model.pt"))
+    W = [p.detach().numpy().T.copy() for p in m.parameters()]    # [in, out]
+    x = list(torch.jit.load(os.path.join(d, "sample_input.pt")).parameters())[0].detach().numpy()
+    want = np.maximum(x.astype(np.float64) @ W[0], 0) @ W[1]
+    for b in range(3):
+        for o in range(4):
+            v = vals[b * 4 + o]
+            v = v - bm.R_MOD if v > bm.R_MOD // 2 else v
+            assert abs(v / 2.0 ** 32 - want[b, o]) < 2e-3
+    # bit-exact against the oracle's quantised forward
+    Wq = [oracle.fr_mont(oracle.float_to_fr(W[0], 8, 8)), oracle.fr_mont(oracle.float_to_fr(W[1], 8, 4))]
+    X = oracle.fr_mont(oracle.float_to_fr(x, 4, 8))
+    A, *_ = oracle.relu_forward(oracle.fc_forward(X, Wq[0], 4, 8, 8))
+    Y = oracle.fr_unmont(oracle.fc_forward(A, Wq[1], 4, 8, 4))
+    assert vals == [bm.limbs_to_int(r) for r in Y]
+
+    # the proof itself, against the oracle
+    _oracle_replay_matches(d, [6, 5, 4], 3, oracle)
+
+
 def test_demo_proves_with_hash_derived_challenges_and_verifies(tmp_path):
     """./demo --fs --verify: challenges from SHA-256(model | input | commitments), then the C++ verifier pass over the
     serialised proof (zkFC::verify / zkReLU::verify -> zk_verify_fc / zk_verify_relu) reads public data only."""
@@ -118,6 +126,28 @@ def test_demo_proves_with_hash_derived_challenges_and_verifies(tmp_path):
     # challenges must differ too)
     second = open(os.path.join(d, "challenges.bin"), "rb").read()
     assert len(first) == len(second) and first != second
+
+
+def test_demo_sound_mode_verifies_and_is_a_reference_transcript(tmp_path, oracle):
+    """./demo --sound --verify: every sumcheck round challenge is a hash of the rounds before it (zkFC::prove_fs / zkReLU::prove_fs); the C++
+    verifier re-derives the challenges from the statement and the proof's own round messages.  Fed those challenges, the CPU oracle
+    reproduces the transcript bit for bit; a second run of the same statement gives the same proof (--repeat checks the digest)."""
+    exe = os.path.join(HOST, "demo")
+    if not os.path.exists(exe):
+        pytest.skip("zkdl_amd/host/demo not built (needs LibTorch)")
+    d = str(tmp_path)
+    dims, batch = [12, 20, 9, 7], 5
+    subprocess.run([sys.executable, "-m", "zkdl_amd.model", "--dims", ",".join(map(str, dims)), "--batch", str(batch), "--seed", "3", "--out-dir", d], check=True, cwd=ROOT)
+    args = [exe, os.path.join(d, "traced_model.pt"), os.path.join(d, "sample_input.pt"), "--sound", "--verify", "--repeat", "1", "--dump", d]
+    run = subprocess.run(args, capture_output=True, text=True, cwd=d, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "Verification: OK" in run.stdout and "digest differs" not in run.stdout
+    _oracle_replay_matches(d, dims, batch, oracle)
+    # the round challenges are NOT the statement-derived ones of --fs: same statement digest domain, different vectors
+    ch_sound = open(os.path.join(d, "challenges.bin"), "rb").read()
+    run_fs = subprocess.run([a if a != "--sound" else "--fs" for a in args], capture_output=True, text=True, cwd=d, timeout=600)
+    assert run_fs.returncode == 0 and "Verification: OK" in run_fs.stdout
+    assert len(open(os.path.join(d, "challenges.bin"), "rb").read()) == len(ch_sound)
 
 
 def test_demo_accepts_linear_layers_with_bias(tmp_path, oracle):
@@ -198,12 +228,18 @@ def test_demo_driver_at_the_headline_configuration(tmp_path):
     warm3 = float(re.search(r"Warm proof time: ([0-9.eE+-]+) seconds per data point", run3.stdout).group(1))
     assert 0 < warm3 < 0.1
     assert [int(x, 16) for x in open(os.path.join(d, "demo.out")).read().strip().strip("[]").split("\n")] == vals
+    # the sound mode (round-by-round Fiat-Shamir) through the same driver
+    run4 = subprocess.run([exe, model_pt, input_pt, "--sound", "--verify", "--repeat", "3", "--full-tables", "12"], capture_output=True, text=True, cwd=d, timeout=900)
+    assert run4.returncode == 0, run4.stdout + run4.stderr
+    assert "Verification: OK" in run4.stdout and "digest differs" not in run4.stdout
+    assert 0 < float(re.search(r"Warm proof time: ([0-9.eE+-]+) seconds per data point", run4.stdout).group(1)) < 0.1
     keep = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(keep):
         with open(os.path.join(keep, "demo_headline.txt"), "w") as f:
             f.write("$ python -m zkdl_amd.model && ./demo traced_model.pt sample_input.pt --seed 5 --repeat 3\n" + run.stdout)
             f.write("\n$ ./demo traced_model.pt sample_input.pt --fs --verify --repeat 1\n" + run2.stdout)
             f.write("\n$ ./demo traced_model.pt sample_input.pt --fs --verify --repeat 3 --full-tables 12\n" + run3.stdout)
+            f.write("\n$ ./demo traced_model.pt sample_input.pt --sound --verify --repeat 3 --full-tables 12\n" + run4.stdout)
 
 
 def test_demo_loads_leaky_identity_and_bare_linear_stacks(tmp_path):

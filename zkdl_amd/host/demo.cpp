@@ -1,5 +1,5 @@
 // zkdl_amd/host/demo.cpp -- the reference driver (demo.cu) on the MI355X library.
-//   ./demo traced_model.pt sample_input.pt [--seed S] [--dump DIR] [--fs] [--verify] [--repeat N] [--gpus N] [--dist] [--full-tables C]
+//   ./demo traced_model.pt sample_input.pt [--seed S] [--dump DIR] [--fs | --sound] [--verify] [--repeat N] [--gpus N] [--dist] [--full-tables C]
 // Same CLI, same inputs (TorchScript nn.Sequential of bias-free Linear + ReLU; a tensor saved as
 // parameter "0" of a scripted empty module, model.py:4-8), same outputs: demo.out (Y_hat, one
 // 0x%064x per line, demo.cu:119-122) and the three stdout lines (demo.cu:92,140-141).
@@ -10,6 +10,9 @@
 // --fs derives the challenges of every prove call from SHA-256(model file | input file | commitments) (zk_fs_derive) instead of
 // the seeded generator; --verify then checks the serialised proof call by call with zk_verify_fc / zk_verify_relu, reading
 // only public data (generators, commitments, the input and output tensors), and prints "Verification: OK" or the failed check.
+// --sound is --fs with every sumcheck ROUND challenge a hash of the rounds before it (zkFC::prove_fs / zkReLU::prove_fs -> zk_fc_prove_fs /
+// zk_relu_prove_fs, the hash running on the device between a round's message and its fold): a prover is bound by each message before it learns the next
+// challenge.  --verify re-derives the challenges from the statement AND the serialised proof's own round messages (zk_fs_round_challenges).
 // --repeat N proves the same statement N more times after the reference's single (cold: first-use allocations, window tables)
 // timed loop and prints the best of them as "Warm proof time: ..." -- the transcript kept is the first run's.
 // --full-tables C: digit tables of every layer's generators (zk_gens_prepare_full, window C bits; 83 GB for the 18M MLP at C = 12), built with the
@@ -214,13 +217,15 @@ int main(int argc, char* argv[]) {
   dist = dist || world > 1;
   string dump_dir;
   vector<Fr_t> challenges;
-  bool use_fs = false, do_verify = false;
+  bool use_fs = false, sound = false, do_verify = false;
+  uint8_t fs_seed[32] = {};
   int repeat = 0;
   for (int i = 3; i < argc; i++) {
     if (string(argv[i]) == "--repeat" && i + 1 < argc) repeat = atoi(argv[i + 1]);
     if (string(argv[i]) == "--seed" && i + 1 < argc) zkdl::seed(strtoull(argv[i + 1], nullptr, 0) + (uint64_t)rank);   // every rank its own generators
     if (string(argv[i]) == "--dump" && i + 1 < argc) dump_dir = argv[i + 1];
     if (string(argv[i]) == "--fs") use_fs = true;
+    if (string(argv[i]) == "--sound") use_fs = sound = true;
     if (string(argv[i]) == "--verify") do_verify = true;
   }
   zkdl::challenge_log() = &challenges;
@@ -267,8 +272,19 @@ int main(int argc, char* argv[]) {
     }
     zk_sha256(st.data(), st.size(), d);
     zkdl::fs_begin(d);
+    memcpy(fs_seed, d, 32);
   }
   auto prove_all = [&]() {   // demo.cu:124-138
+    if (sound) {
+      fcs[num_layer - 1].prove_fs(A_vec[num_layer - 2], Y_hat, *generators[num_layer - 1], fs_seed, num_layer - 1);
+      for (int i = num_layer - 2; i >= 0; --i) {
+        relus[i].prove_fs(Z_vec[i], A_vec[i], fs_seed, i);
+        fcs[i].prove_fs((i > 0) ? A_vec[i - 1] : X, Z_vec[i], *generators[i], fs_seed, i);
+      }
+      zk_transcript_flush(zkdl::transcript());
+      zk_ctx_sync(zkdl::ctx());
+      return;
+    }
     if (use_fs) zkdl::fs_call(num_layer - 1, 0);
     fcs[num_layer - 1].prove(A_vec[num_layer - 2], Y_hat, *generators[num_layer - 1]);
     for (int i = num_layer - 2; i >= 0; --i) {
@@ -301,6 +317,45 @@ int main(int argc, char* argv[]) {
     zk_transcript_serialize(zkdl::transcript(), nullptr, 0, &len);
     first_blob.resize(len);
     zkdl::check(zk_transcript_serialize(zkdl::transcript(), first_blob.data(), first_blob.size(), &len));
+  }
+  if (sound && (do_verify || !dump_dir.empty())) {
+    // the verifier's derivation: evaluation points from the statement digest, round challenges from the proof's own round messages
+    challenges.clear();
+    const Fr_t* fr = reinterpret_cast<const Fr_t*>(first_blob.data() + 24);
+    const uint B_p = 1u << ceilLog2(batch_size);
+    size_t off = 0;
+    auto derived = [&](uint layer, uint kind, uint vec, uint len) {
+      vector<Fr_t> v(len);
+      zkdl::check(zk_fs_derive(fs_seed, layer, kind, vec, len, v.data()));
+      challenges.insert(challenges.end(), v.begin(), v.end());
+    };
+    auto rounds = [&](uint layer, uint kind, uint which, size_t at, uint k) {
+      vector<Fr_t> v(k);
+      if (at + 3 * (size_t)k > n_fr) throw std::runtime_error("transcript does not have the shape of this model's proof");
+      zkdl::check(zk_fs_round_challenges(fs_seed, layer, kind, which, fr + at, k, v.data()));
+      challenges.insert(challenges.end(), v.begin(), v.end());
+    };
+    auto fc_ch = [&](uint i) {
+      const uint k_in = ceilLog2(fcs[i].inputSize), k_out = ceilLog2(fcs[i].outputSize);
+      derived(i, 0, 0, ceilLog2(B_p));
+      rounds(i, 0, 0, off, k_in);
+      derived(i, 0, 2, k_out);
+      off += 3 * k_in + 4;
+    };
+    fc_ch(num_layer - 1);
+    for (int i = num_layer - 2; i >= 0; --i) {
+      const uint k = ceilLog2(B_p * fcs[i].outputSize);
+      const size_t o_mag = off, o_rem = off + 3 * (k + 5) + 1 + 32, o_hp = o_rem + 3 * (k + 4) + 1 + 16;
+      derived(i, 1, 0, k + 5);
+      rounds(i, 1, 1, o_mag, k + 5);
+      derived(i, 1, 2, k + 4);
+      rounds(i, 1, 2, o_rem, k + 4);
+      derived(i, 1, 4, k);
+      derived(i, 1, 5, k);
+      rounds(i, 1, 3, o_hp, k);
+      off = o_hp + 3 * k + 2;
+      fc_ch(i);
+    }
   }
   const vector<Fr_t> first_challenges = challenges;
   if (repeat > 0) {

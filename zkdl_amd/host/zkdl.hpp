@@ -487,6 +487,12 @@ class zkFC {
     zkdl::check(zk_fc_prove(zkdl::ctx(), h_, X.gpu_data, X.size, Z.gpu_data, Z.size, generators.handle(), u_bs.data(), u_in_dim.data(), u_out_dim.data(),
                             zkdl::transcript()));
   }
+  // additive: the round-by-round Fiat-Shamir prover (include/zkdl_amd.h: zk_fc_prove_fs).  u_bs and u_out_dim are derived from the statement
+  // digest, every round challenge of the inner-product sumcheck (u_in_dim) from a hash of the rounds before it, on the device.
+  void prove_fs(const FrTensor& X, const FrTensor& Z, Commitment& generators, const uint8_t seed32[32], uint layer) const {
+    if (X.size % inputSize != 0) throw std::runtime_error("Incompatible dimensions 1");
+    zkdl::check(zk_fc_prove_fs(zkdl::ctx(), h_, X.gpu_data, X.size, Z.gpu_data, Z.size, generators.handle(), seed32, layer, zkdl::transcript()));
+  }
   // additive (the reference has no verifier): check this layer's slice of a serialised proof against the layer's public
   // commitment; challenges in zkfc.cu:135-137's order.  Returns the first failed check's message, empty when it verifies.
   std::string verify(uint batch_size, const Commitment& generators, bool z_is_raw, const std::vector<Fr_t>& u_bs, const std::vector<Fr_t>& u_in_dim,
@@ -549,6 +555,12 @@ class zkReLU {
     }
     zkdl::check(zk_relu_prove(zkdl::ctx(), h_, X.gpu_data, Z.gpu_data, X.size, u_z_bin.data(), v_z_bin.data(), u_r_bin.data(), v_r_bin.data(), u_recover.data(),
                               u_hp.data(), v_hp.data(), zkdl::transcript()));
+  }
+  // additive: round-by-round Fiat-Shamir (zk_relu_prove_fs): v_z, v_r, v_hp are hashes of the rounds before them; ReLU layers only
+  void prove_fs(const FrTensor& X, const FrTensor& Z, const uint8_t seed32[32], uint layer) {
+    if (X.size != Z.size) throw std::runtime_error("Incompatible dimensions");
+    if (kind_ == 1) throw std::runtime_error("round-by-round Fiat-Shamir: LeakyReLU layers have no prover in this mode");
+    zkdl::check(zk_relu_prove_fs(zkdl::ctx(), h_, X.gpu_data, Z.gpu_data, X.size, seed32, layer, zkdl::transcript()));
   }
   // additive: the verifier's checks of one zkReLU::prove slice (challenge vectors in zkrelu.cu:85-98's order; u_recover enters no
   // check); claims5 receives the five evaluations the reference leaves unbound
