@@ -257,6 +257,12 @@ def test_demo_loads_leaky_identity_and_bare_linear_stacks(tmp_path):
     run = subprocess.run([exe, os.path.join(d, "traced_model.pt"), os.path.join(d, "sample_input.pt"), "--fs", "--verify"], capture_output=True, text=True, cwd=d, timeout=600)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "Verification: OK" in run.stdout
+    # the same model in the sound mode: the extra sumchecks' round challenges are hashes of their own earlier rounds too
+    run_s = subprocess.run([exe, os.path.join(d, "traced_model.pt"), os.path.join(d, "sample_input.pt"), "--sound", "--verify", "--repeat", "1"], capture_output=True, text=True,
+                           cwd=d, timeout=600)
+    assert run_s.returncode == 0, run_s.stdout + run_s.stderr
+    assert "Verification: OK" in run_s.stdout and "digest differs" not in run_s.stdout
+    assert run_s.stdout.split("Transcript: ")[1].split(" Fr")[0] == run.stdout.split("Transcript: ")[1].split(" Fr")[0]
     vals = [int(x, 16) for x in open(os.path.join(d, "demo.out")).read().strip().strip("[]").split("\n")]
     assert len(vals) == 8 * 8
     m = torch.jit.load(os.path.join(d, "traced_model.pt"))

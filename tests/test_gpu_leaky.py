@@ -76,6 +76,59 @@ def test_leaky_forward_and_proof_match_the_oracle(zk, oracle, n, shift):
     tr.close()
 
 
+@pytest.mark.parametrize("n,shift", [(1, 3), (700, 3), (5000, 0)])
+def test_leaky_sound_mode_is_a_reference_transcript_and_verifies(zk, oracle, n, shift):
+    """zk_leaky_prove_fs: every sumcheck round challenge (v_z, v_r, v_hp, v_lk) is a hash of the rounds before it.  The verifier's derivation
+    (statement digest + the proof's own round messages) gives nine vectors with which zk_leaky_prove AND the CPU oracle reproduce the
+    transcript bit for bit, and zk_verify_leaky accepts; a changed round message changes the later challenges and is rejected."""
+    from zkdl_amd.capi import ReLU, Transcript, fs_derive, fs_round_challenges
+    import bigint_model as bm
+    rng = np.random.default_rng(300 + n + shift)
+    vals = [int(x) for x in rng.integers(-(1 << 40), 1 << 40, size=n)]
+    X = np.array([bm.fr_to_mont(v % bm.R_MOD) for v in vals], dtype=np.uint32).reshape(-1, 8)
+    A_o, sign_o, mag_o, rem_o, low_o, nsign_o = oracle.leaky_forward(X, shift)
+    relu = ReLU(zk)
+    relu.set_activation(1, shift)
+    xd = zk.upload(X)
+    a = relu.forward(xd)
+    seed, layer = bytes(range(32)), 3
+    tr = Transcript(zk)
+    relu.prove_leaky_fs(xd, a, seed, layer, tr)
+    fr, _ = tr.read()
+    tr.close()
+    k = oracle.ceil_log2(n)
+    o_rem = 3 * (k + 5) + 1 + 32
+    o_hp = o_rem + 3 * (k + 4) + 1 + 16
+    o_lk = o_hp + 3 * k + 2
+    assert fr.shape[0] == o_lk + 3 * k + 2
+
+    def challenges(fr):
+        return [fs_derive(seed, layer, 1, 0, k + 5), fs_round_challenges(seed, layer, 1, 1, fr[:3 * (k + 5)]),
+                fs_derive(seed, layer, 1, 2, k + 4), fs_round_challenges(seed, layer, 1, 2, fr[o_rem:o_rem + 3 * (k + 4)]),
+                fs_derive(seed, layer, 1, 4, k), fs_derive(seed, layer, 1, 5, k), fs_round_challenges(seed, layer, 1, 3, fr[o_hp:o_hp + 3 * k]),
+                fs_derive(seed, layer, 1, 7, k), fs_round_challenges(seed, layer, 1, 4, fr[o_lk:o_lk + 3 * k])]
+
+    ch = challenges(fr)
+    assert eq(fr, oracle.leaky_prove(X, A_o, sign_o, mag_o, rem_o, low_o, nsign_o, *ch))
+    tr = Transcript(zk)
+    relu.prove_leaky(xd, a, ch, tr)
+    assert eq(tr.read()[0], fr)
+    tr.close()
+    ok, msg, _ = zk.verify_leaky(n, ch, fr)
+    assert ok, msg
+    if k > 1:
+        bad = fr.copy()
+        bad[o_lk + 1, 0] ^= 1                                # round 0 of the extra sumcheck: c1
+        assert not zk.verify_leaky(n, challenges(bad), bad)[0]
+    # a ReLU layer has no leaky transcript
+    plain = ReLU(zk)
+    plain.forward(xd)
+    tr = Transcript(zk)
+    with pytest.raises(Exception):
+        plain.prove_leaky_fs(xd, a, seed, layer, tr)
+    tr.close()
+
+
 def test_mlp_with_leaky_and_identity_activations_matches_the_float_model(zk, oracle):
     """Linear(20, 24) -> LeakyReLU(1/8) -> Linear(24, 16) -> Identity -> Linear(16, 5): quantised inference through the C ABI equals the
     oracle's bit for bit and de-quantises to the float network (floor rounding on the negative branch: one unit of 2^-16 per layer)."""

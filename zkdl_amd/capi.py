@@ -34,7 +34,7 @@ zk_fc_out zk_fc_com_size zk_fc_weights zk_fc_com zk_fc_load_input zk_fc_forward 
 zk_relu_destroy zk_relu_forward zk_relu_sign zk_relu_mag_bin zk_relu_rem_bin zk_relu_prove zk_transcript_create
 zk_transcript_destroy zk_transcript_reset zk_transcript_flush zk_transcript_counts zk_transcript_read zk_transcript_read_affine
 zk_transcript_digest zk_transcript_digest_dev zk_transcript_serialize zk_transcript_seal zk_transcript_seal_pair zk_transcript_stream
-zk_verify_fc zk_verify_relu zk_verify_open zk_fs_derive zk_sha256 zk_fc_prove_fs zk_relu_prove_fs zk_fs_round_challenges zk_relu_set_activation zk_leaky_prove zk_verify_leaky zk_act_open zk_verify_act_open zk_dist_unique_id zk_dist_init zk_dist_world_size zk_dist_sum_rows zk_dist_allreduce_u64
+zk_verify_fc zk_verify_relu zk_verify_open zk_fs_derive zk_sha256 zk_fc_prove_fs zk_relu_prove_fs zk_leaky_prove_fs zk_fs_round_challenges zk_relu_set_activation zk_leaky_prove zk_verify_leaky zk_act_open zk_verify_act_open zk_dist_unique_id zk_dist_init zk_dist_world_size zk_dist_sum_rows zk_dist_allreduce_u64
 zk_dist_lanes_to_fr zk_dist_destroy zk_gens_prepare_full""".split()
 
 
@@ -761,6 +761,11 @@ class ReLU:
         """zkReLU::prove with round-by-round Fiat-Shamir challenges (zk_relu_prove_fs)."""
         zk = self.zk
         zk._chk(zk.lib.zk_relu_prove_fs(zk.ctx, self.h, _vp(x.ptr), _vp(z.ptr), _u32(x.n), bytes(seed32), _u32(layer), tr.h))
+
+    def prove_leaky_fs(self, x, z, seed32, layer, tr):
+        """zk_leaky_prove with round-by-round Fiat-Shamir challenges (zk_leaky_prove_fs)."""
+        zk = self.zk
+        zk._chk(zk.lib.zk_leaky_prove_fs(zk.ctx, self.h, _vp(x.ptr), _vp(z.ptr), _u32(x.n), bytes(seed32), _u32(layer), tr.h))
 
     def close(self):
         if self.h:

@@ -459,6 +459,33 @@ int relu_prove_fs(zk_ctx* ctx, const zk_relu* relu, const Fr* x, uint32_t n, con
   FsGuard guard(ctx, tr);
   return guard.finish(relu_prove_fs_body(ctx, relu, x, n, seed32, layer, tr));
 }
+// zk_leaky_prove with round-by-round challenges: zkReLU's transcript, then hadamard_product_sumcheck(low, 1 - sign, u_lk, v_lk) with u_lk
+// statement-derived (vec 7 of the layer's draw order) and v_lk the hash chain "which = 4"
+int leaky_prove_fs(zk_ctx* ctx, const zk_relu* relu, const Fr* x, uint32_t n, const uint8_t* seed32, uint32_t layer, zk_transcript* tr) {
+  if (relu->act_kind != 1 || !relu->low) return ctx->fail(ZK_ERR_ARG, "zk_leaky_prove_fs: the layer's last forward pass was not a LeakyReLU one");
+  FsGuard guard(ctx, tr);
+  int rc = relu_prove_fs_body(ctx, relu, x, n, seed32, layer, tr);
+  if (rc != ZK_OK) return guard.finish(rc);
+  const uint32_t k = ceil_log2(n);
+  const size_t add_fr = 3 * k + 2;
+  rc = tr->ensure(add_fr, 0);
+  if (rc != ZK_OK) return guard.finish(rc);
+  Fr* out = tr->fr_d + tr->n_fr;
+  tr->n_fr += add_fr;
+  auto body = [&]() -> int {
+    RecScope recording(ctx, &tr->rec, REC_GROUP_FC_A);
+    if (recording.rc != ZK_OK) return recording.rc;
+    LaneScope lane(ctx, recording.on ? ~0u : relu->serial);
+    std::vector<zk_fr> ch(2 * k, zk_fr{});
+    if (k) ZK_TRY(zk_fs_derive(seed32, layer, 1, 7, k, ch.data()));
+    put_state(ch, fs_state0(seed32, layer, 1, 4));
+    DBuf<Fr> chd;
+    ZK_TRY(upload_fr(ctx, chd, ch.data(), (uint32_t)ch.size()));
+    Fr* c = chd.get();
+    return run_sumcheck_fs<FSC_HP>(ctx, relu->low, relu->nsign, n, reinterpret_cast<FsState*>(c + 2 * k), c + k, c, k, out);
+  };
+  return guard.finish(body());
+}
 
 }  // namespace zk
 
@@ -482,6 +509,15 @@ int zk_relu_prove_fs(zk_ctx* ctx, const zk_relu* relu, const zk_fr* x_d, const z
   if (!relu || !tr || !seed32 || !x_d) return ctx->fail(ZK_ERR_ARG, "zk_relu_prove_fs: null argument");
   if (((uintptr_t)x_d) & 15u) return ctx->fail(ZK_ERR_ARG, "misaligned device pointer");
   return relu_prove_fs(ctx, relu, reinterpret_cast<const Fr*>(x_d), n, seed32, layer, tr);
+}
+
+int zk_leaky_prove_fs(zk_ctx* ctx, const zk_relu* relu, const zk_fr* x_d, const zk_fr* z_d, uint32_t n, const uint8_t* seed32, uint32_t layer, zk_transcript* tr) {
+  (void)z_d;
+  if (!ctx) return ZK_ERR_ARG;
+  (void)hipSetDevice(ctx->device);
+  if (!relu || !x_d || !seed32 || !tr) return ctx->fail(ZK_ERR_ARG, "zk_leaky_prove_fs: null argument");
+  if (((uintptr_t)x_d) & 15u) return ctx->fail(ZK_ERR_ARG, "misaligned device pointer");
+  return leaky_prove_fs(ctx, relu, reinterpret_cast<const Fr*>(x_d), n, seed32, layer, tr);
 }
 
 // The verifier's side of the round challenges: coeffs_h holds the k rounds' coefficient triples as the proof carries them.

@@ -354,6 +354,11 @@ int main(int argc, char* argv[]) {
       derived(i, 1, 5, k);
       rounds(i, 1, 3, o_hp, k);
       off = o_hp + 3 * k + 2;
+      if (relus[i].leaky()) {   // the extra Hadamard sumcheck of a LeakyReLU / identity layer
+        derived(i, 1, 7, k);
+        rounds(i, 1, 4, off, k);
+        off += 3 * k + 2;
+      }
       fc_ch(i);
     }
   }

@@ -556,10 +556,13 @@ class zkReLU {
     zkdl::check(zk_relu_prove(zkdl::ctx(), h_, X.gpu_data, Z.gpu_data, X.size, u_z_bin.data(), v_z_bin.data(), u_r_bin.data(), v_r_bin.data(), u_recover.data(),
                               u_hp.data(), v_hp.data(), zkdl::transcript()));
   }
-  // additive: round-by-round Fiat-Shamir (zk_relu_prove_fs): v_z, v_r, v_hp are hashes of the rounds before them; ReLU layers only
+  // additive: round-by-round Fiat-Shamir (zk_relu_prove_fs / zk_leaky_prove_fs): v_z, v_r, v_hp (and v_lk) are hashes of the rounds before them
   void prove_fs(const FrTensor& X, const FrTensor& Z, const uint8_t seed32[32], uint layer) {
     if (X.size != Z.size) throw std::runtime_error("Incompatible dimensions");
-    if (kind_ == 1) throw std::runtime_error("round-by-round Fiat-Shamir: LeakyReLU layers have no prover in this mode");
+    if (kind_ == 1) {   // one more Hadamard sumcheck, its round challenges the hash chain which = 4 (zk_leaky_prove_fs)
+      zkdl::check(zk_leaky_prove_fs(zkdl::ctx(), h_, X.gpu_data, Z.gpu_data, X.size, seed32, layer, zkdl::transcript()));
+      return;
+    }
     zkdl::check(zk_relu_prove_fs(zkdl::ctx(), h_, X.gpu_data, Z.gpu_data, X.size, seed32, layer, zkdl::transcript()));
   }
   // additive: the verifier's checks of one zkReLU::prove slice (challenge vectors in zkrelu.cu:85-98's order; u_recover enters no
