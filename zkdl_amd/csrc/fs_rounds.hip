@@ -431,13 +431,15 @@ static int relu_prove_fs_body(zk_ctx* ctx, const zk_relu* relu, const Fr* x, uin
   FsState* states = reinterpret_cast<FsState*>(c + tot);
   DBuf<Fr> t3_mag, t3_rem;  // declared behind the lane scope: released into the recording's deferred frees
   if (packed) {
-    // rounds 0..2 from the packed words (one weighted byte histogram, taken before any challenge exists), the rest on the table V3[byte]
-    ZK_TRY(fsb_sumcheck_head_dev(ctx, relu->mag_packed, n, 32, c + offs[0], k + 5, states + 0, c + offs[1], out, c + offs[4], out + 3 * (k + 5) + 1, t3_mag));
-    ZK_TRY(run_sumcheck_fs<FSC_BIN>(ctx, t3_mag.get(), nullptr, n * 4, states + 0, c + offs[1] + 3, c + offs[0] + 3, k + 2, out + 9));
+    // the in-word rounds from the packed words (weighted byte histograms, the first taken before any challenge exists), the rest on a table of
+    // one entry per word
+    uint32_t R = 0;
+    ZK_TRY(fsb_sumcheck_head_dev(ctx, relu->mag_packed, n, 32, c + offs[0], k + 5, states + 0, c + offs[1], out, c + offs[4], out + 3 * (k + 5) + 1, t3_mag, &R));
+    ZK_TRY(run_sumcheck_fs<FSC_BIN>(ctx, t3_mag.get(), nullptr, n, states + 0, c + offs[1] + R, c + offs[0] + R, k + 5 - R, out + 3 * R));
     out += 3 * (k + 5) + 1 + 32;
     rec_split(ctx, REC_GROUP_RELU_REM);
-    ZK_TRY(fsb_sumcheck_head_dev(ctx, relu->rem_packed, n, 16, c + offs[2], k + 4, states + 1, c + offs[3], out, c + offs[4], out + 3 * (k + 4) + 1, t3_rem));
-    ZK_TRY(run_sumcheck_fs<FSC_BIN>(ctx, t3_rem.get(), nullptr, n * 2, states + 1, c + offs[3] + 3, c + offs[2] + 3, k + 1, out + 9));
+    ZK_TRY(fsb_sumcheck_head_dev(ctx, relu->rem_packed, n, 16, c + offs[2], k + 4, states + 1, c + offs[3], out, c + offs[4], out + 3 * (k + 4) + 1, t3_rem, &R));
+    ZK_TRY(run_sumcheck_fs<FSC_BIN>(ctx, t3_rem.get(), nullptr, n, states + 1, c + offs[3] + R, c + offs[2] + R, k + 4 - R, out + 3 * R));
     out += 3 * (k + 4) + 1 + 16;
   } else {
     ZK_TRY(run_sumcheck_fs<FSC_BIN>(ctx, relu->mag_bin, nullptr, n * 32, states + 0, c + offs[1], c + offs[0], k + 5, out));

@@ -115,9 +115,10 @@ int transcript_digest_dev(zk_ctx* ctx, const Fr* fr, size_t n_fr, const G1J* g1,
 int binp_sumcheck_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb, const Fr* u_d, const Fr* v_d, uint32_t k, Fr* proof_d);
 int binp_partial_me_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb, const Fr* u_d, uint32_t k, Fr* out_d);
 int binb_sumcheck_pme_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb, const Fr* u_d, const Fr* v_d, uint32_t k, Fr* proof_d, const Fr* u_rec_d, Fr* pme_d);
-// sound mode: rounds 0..2 of the bit sumcheck from the packed words, hashing between the rounds (state_d: FsState*); t3 receives the table of round 3
+// sound mode: the in-word rounds (5 for 32-bit words, 4 for 16-bit words) of the bit sumcheck from the packed words, hashing between the rounds
+// (state_d: FsState*); t receives the table of the next round, one entry per word
 int fsb_sumcheck_head_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb, const Fr* u_d, uint32_t k, void* state_d, Fr* fold_d, Fr* proof_d, const Fr* u_rec_d, Fr* pme_d,
-                          DBuf<Fr>& t3);
+                          DBuf<Fr>& t, uint32_t* rounds_done);
 int float_to_fr_dev(zk_ctx* ctx, const float* fs, Fr* out, uint32_t rows, uint32_t rows_p, uint32_t cols, uint32_t cols_p);
 int gens_create(zk_ctx* ctx, const G1J* gens_d, uint32_t n, bool copy, zk_gens** out);
 void gens_destroy(zk_gens* g);

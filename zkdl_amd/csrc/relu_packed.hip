@@ -767,7 +767,7 @@ __device__ __forceinline__ void k_fsb_hist(uint32_t zk_nblk, const WordT* __rest
 // One workgroup of 1024 lanes, one histogram bin (p, e) per lane.  proof[0..9): the messages of rounds 0..2; fold[0..3): x_0..x_2;
 // v3tab[256]; pme_out[nb]; *state advanced by three rounds.
 __device__ __forceinline__ void k_fsb_rounds(uint32_t zk_nblk, const unsigned long long* __restrict__ sums, BytesLayout L, const Fr* __restrict__ u, Fr* __restrict__ fold,
-                                                     FsState* __restrict__ state, Fr* __restrict__ proof, Fr* __restrict__ pme_out, Fr* __restrict__ v3tab) {
+                                                     FsState* __restrict__ state, Fr* __restrict__ proof, Fr* __restrict__ pme_out, Fr* __restrict__ v3tab, Fr* __restrict__ hfr) {
   __shared__ Fr red[48];
   __shared__ Fr elo[28];
   __shared__ Fr xs[3];
@@ -783,7 +783,10 @@ __device__ __forceinline__ void k_fsb_rounds(uint32_t zk_nblk, const unsigned lo
   const bool own = tid < L.nH;  // nH <= blockDim.x = 1024
   const uint32_t p = tid >> 8, e = tid & 255u;
   Fr h = fr_zero();
-  if (own) h = binb_bin_to_fr(sums + (size_t)tid * BINB_LIMBS_LDS * 2);
+  if (own) {
+    h = binb_bin_to_fr(sums + (size_t)tid * BINB_LIMBS_LDS * 2);
+    hfr[tid] = h;  // rounds 3 and 4 (k_fsb_round3 / k_fsb_round4) contract the same histogram with their own factors
+  }
   const bool live = own && !l_is_zero(h);
   FsState st;
   if (tid == 0) st = *state;
@@ -881,36 +884,196 @@ __device__ __forceinline__ void k_fsb_rounds(uint32_t zk_nblk, const unsigned lo
   }
 }
 
-// out[i] = V3[byte i]: the table of round 3
-__device__ __forceinline__ void k_fsb_expand(uint32_t zk_nblk, const uint8_t* __restrict__ bytes, uint32_t n3, const Fr* __restrict__ v3tab, Fr* __restrict__ out) {
-  __shared__ Fr V3[256];
+// ---- rounds 3 and 4, still inside a word.  Their coefficient sums are, again, contractions of H with per-bin factors (now functions of
+// V3, i.e. of x_0..x_2, and for round 4 of x_3) PLUS the terms that are not functions of single bytes (k_binb_finish):
+//   round 3: c2 -= 2 sum_j eq(u[4..lognb), j) SX_j,   SX_j = sum_g w_g V3[byte_2j(g)] V3[byte_2j+1(g)]
+//   round 4 (32-bit words): c0 += m SX_0, p1 += m SX_1, c2 += m (SX_0 + SX_1) - 2 A,   m = 2 (1 - x_3) x_3,   A = sum_g w_g a0(g) a1(g)
+// SX needs V3 (a pass over the words behind round 2: k_fsb_cross, a histogram keyed by the low byte of each byte pair), A needs x_3 (a
+// pass behind round 3: k_fsb_prodA).  The table the generic rounds start from has ONE entry per word (k_fsb_out, behind the last of these).
+template <int NB, class WordT>
+__device__ __forceinline__ void k_fsb_cross(uint32_t zk_nblk, const WordT* __restrict__ packed, uint32_t n, const Fr* __restrict__ AH, const Fr* __restrict__ BH, uint32_t ch,
+                                                    const Fr* __restrict__ v3tab, unsigned long long* __restrict__ slabs) {
+  constexpr uint32_t NPAIR = NB / 16, NBINS = NPAIR * 256;
+  extern __shared__ unsigned long long lds64[];
+  unsigned long long* H = lds64;
+  Fr* V3 = reinterpret_cast<Fr*>(lds64 + NBINS * BINB_LIMBS_LDS);
+  for (uint32_t i = threadIdx.x; i < NBINS * BINB_LIMBS_LDS; i += blockDim.x) H[i] = 0ull;
   for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) V3[i] = v3tab[i];
   __syncthreads();
-  // four consecutive bytes per lane and step (one 32-bit load)
-  const uint32_t n4 = n3 / 4;
-  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += zk_nblk * blockDim.x) {
-    const uint32_t w = reinterpret_cast<const uint32_t*>(bytes)[q];
+  const uint32_t mh = (1u << ch) - 1u;
+  const uint32_t per = (n + zk_nblk - 1) / zk_nblk;
+  const uint32_t g_end = min(n, (blockIdx.x + 1) * per);
+  for (uint32_t g = blockIdx.x * per + threadIdx.x; g < g_end; g += blockDim.x) {
+    const uint32_t word = packed[g];
+    bool any = false;
 #pragma unroll
-    for (uint32_t j = 0; j < 4; j++) {
-      const uint32_t b = (w >> (8 * j)) & 255u;
-      out[4 * (size_t)q + j] = b ? V3[b] : fr_zero();
+    for (uint32_t j = 0; j < NPAIR; j++) any = any || (((word >> (16 * j)) & 255u) && ((word >> (16 * j + 8)) & 255u));
+    if (!any) continue;
+    const Fr w = fr_mul(AH[g & mh], BH[g >> ch]);
+#pragma unroll
+    for (uint32_t j = 0; j < NPAIR; j++) {
+      const uint32_t b0 = (word >> (16 * j)) & 255u, b1 = (word >> (16 * j + 8)) & 255u;
+      if (b0 && b1) binb_hist_add(H + (j * 256 + b0) * BINB_LIMBS_LDS, fr_mul(w, V3[b1]));
     }
   }
-  if (blockIdx.x == 0) {
-    for (uint32_t i = 4 * n4 + threadIdx.x; i < n3; i += blockDim.x) out[i] = V3[bytes[i]];
+  __syncthreads();
+  unsigned long long* dst = slabs + (size_t)blockIdx.x * NBINS * BINB_LIMBS_LDS;
+  for (uint32_t i = threadIdx.x; i < NBINS * BINB_LIMBS_LDS; i += blockDim.x) dst[i] = H[i];
+}
+
+// One workgroup of 1024 lanes: round 3's message from the stored histogram and the cross-term sums, the hash step, and what x_3 unlocks:
+// tabAB = [VA = (1 - x_3) V3 | VB = x_3 V3] (512 entries) and sx[0..2) for round 4
+__device__ __forceinline__ void k_fsb_round3(uint32_t zk_nblk, const Fr* __restrict__ hfr, const unsigned long long* __restrict__ xsums, BytesLayout L, const Fr* __restrict__ u,
+                                                     const Fr* __restrict__ v3tab, Fr* __restrict__ fold, FsState* __restrict__ state, Fr* __restrict__ proof, Fr* __restrict__ tabAB,
+                                                     Fr* __restrict__ sx_out) {
+  __shared__ Fr red[48];
+  __shared__ Fr xs[1];
+  const uint32_t tid = threadIdx.x;
+  const bool own = tid < L.nH;
+  const uint32_t p = tid >> 8, e = tid & 255u;
+  const Fr zero = fr_zero(), one = fr_one();
+  Fr c0 = zero, p1 = zero, c2 = zero;
+  const Fr t = v3tab[e];
+  if (own) {
+    const Fr h = hfr[tid];
+    if (!l_is_zero(h) && e) {
+      const Fr w = fr_mul(eq_prod(u + 4, L.lognb - 4, p >> 1), h), sq = fr_sqr(t);
+      const Fr q = fr_mul(w, fr_sub(sq, t));
+      if (p & 1u) p1 = q;
+      else c0 = q;
+      c2 = fr_mul(w, sq);
+    }
+  }
+  block_sum3_fr(c0, p1, c2, red);
+  Fr sx0 = zero, sx1 = zero, z2 = zero;
+  if (tid < L.nHP) {
+    const Fr hp = binb_bin_to_fr(xsums + (size_t)tid * BINB_LIMBS_LDS * 2);
+    if (!l_is_zero(hp)) {
+      const Fr v = fr_mul(t, hp);   // t = V3[tid & 255]
+      if (tid < 256) sx0 = v;
+      else sx1 = v;
+    }
+  }
+  block_sum3_fr(sx0, sx1, z2, red);
+  if (tid == 0) {
+    Fr cross = sx0;
+    if (L.lognb == 5) {
+      const Fr u4 = u[4];
+      cross = fr_add(fr_mul(fr_sub(one, u4), sx0), fr_mul(u4, sx1));
+    }
+    c2 = fr_sub(c2, fr_dbl(cross));
+    const Fr c1 = fr_sub(fr_sub(p1, c0), c2);
+    proof[0] = c0;
+    proof[1] = c1;
+    proof[2] = c2;
+    FsState st = *state;
+    const Fr x = fs_round_step(st, c0, c1, c2);
+    *state = st;
+    fold[0] = x;
+    xs[0] = x;
+    sx_out[0] = sx0;
+    sx_out[1] = sx1;
+  }
+  __syncthreads();
+  if (tid < 512) {
+    const Fr x3 = xs[0];
+    tabAB[tid] = fr_mul(tid < 256 ? fr_sub(one, x3) : x3, t);
   }
 }
 
-// rounds 0..2 (messages into proof_d[0..9), x_0..x_2 into fold_d[0..3), *state_d advanced), partial_me(u_rec, nb) into pme_d, and the
-// table of round 3 (n * nb / 8 entries) into t3
+// A = sum_g w_g a0(g) a1(g) over 32-bit words, a0 = VA[b0] + VB[b1], a1 = VA[b2] + VB[b3]: per-workgroup partials
+__device__ __forceinline__ void k_fsb_prodA(uint32_t zk_nblk, const uint32_t* __restrict__ packed, uint32_t n, const Fr* __restrict__ AH, const Fr* __restrict__ BH, uint32_t ch,
+                                                    const Fr* __restrict__ tabAB, Fr* __restrict__ partialA) {
+  __shared__ Fr tab[512];
+  __shared__ Fr red[16];
+  for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) tab[i] = tabAB[i];
+  __syncthreads();
+  const uint32_t mh = (1u << ch) - 1u;
+  Fr acc = fr_zero();
+  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += zk_nblk * blockDim.x) {
+    const uint32_t word = packed[g];
+    if ((word & 0xffffu) == 0u || (word >> 16) == 0u) continue;
+    const Fr a0 = fr_add(tab[word & 255u], tab[256 + ((word >> 8) & 255u)]), a1 = fr_add(tab[(word >> 16) & 255u], tab[256 + (word >> 24)]);
+    acc = fr_add(acc, fr_mul(fr_mul(fr_mul(AH[g & mh], BH[g >> ch]), a0), a1));
+  }
+  acc = block_sum_fr(acc, red);
+  if (threadIdx.x == 0) partialA[blockIdx.x] = acc;
+}
+
+// One workgroup of 1024 lanes (32-bit words): round 4's message and x_4
+__device__ __forceinline__ void k_fsb_round4(uint32_t zk_nblk, const Fr* __restrict__ hfr, const Fr* __restrict__ v3tab, const Fr* __restrict__ x3p, const Fr* __restrict__ sx,
+                                                     const Fr* __restrict__ partialA, uint32_t nA, Fr* __restrict__ fold, FsState* __restrict__ state, Fr* __restrict__ proof) {
+  __shared__ Fr red[48];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t p = tid >> 8, e = tid & 255u;
+  const Fr zero = fr_zero(), one = fr_one();
+  const Fr v3 = x3p[0];
+  Fr c0 = zero, p1 = zero, c2 = zero;
+  {
+    const Fr h = hfr[tid];   // nH = 1024 = blockDim.x
+    if (!l_is_zero(h) && e) {
+      const Fr t = v3tab[e], c = (p & 1u) ? v3 : fr_sub(one, v3);
+      const Fr c2sq = fr_mul(fr_mul(fr_sqr(c), fr_sqr(t)), h), q = fr_sub(c2sq, fr_mul(fr_mul(c, t), h));
+      if (p < 2) c0 = q;
+      else p1 = q;
+      c2 = c2sq;
+    }
+  }
+  block_sum3_fr(c0, p1, c2, red);
+  Fr A = zero, z1 = zero, z2 = zero;
+  for (uint32_t i = tid; i < nA; i += blockDim.x) A = fr_add(A, partialA[i]);
+  block_sum3_fr(A, z1, z2, red);
+  if (tid == 0) {
+    const Fr m = fr_dbl(fr_mul(fr_sub(one, v3), v3));
+    const Fr m0 = fr_mul(m, sx[0]), m1 = fr_mul(m, sx[1]);
+    c0 = fr_add(c0, m0);
+    p1 = fr_add(p1, m1);
+    c2 = fr_sub(fr_add(c2, fr_add(m0, m1)), fr_dbl(A));
+    const Fr c1 = fr_sub(fr_sub(p1, c0), c2);
+    proof[0] = c0;
+    proof[1] = c1;
+    proof[2] = c2;
+    FsState st = *state;
+    fold[0] = fs_round_step(st, c0, c1, c2);
+    *state = st;
+  }
+}
+
+// the table the generic rounds start from, one entry per word: a0 + x_4 (a1 - a0) (32-bit words; x4p = the challenge of round 4), a0 (16-bit words)
+template <int NB, class WordT>
+__device__ __forceinline__ void k_fsb_out(uint32_t zk_nblk, const WordT* __restrict__ packed, uint32_t n, const Fr* __restrict__ tabAB, const Fr* __restrict__ x4p, Fr* __restrict__ out) {
+  __shared__ Fr tab[512];
+  for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) tab[i] = tabAB[i];
+  __syncthreads();
+  Fr x4 = fr_zero();
+  if (NB == 32) x4 = x4p[0];
+  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += zk_nblk * blockDim.x) {
+    const uint32_t word = packed[g];
+    if (word == 0u) {
+      out[g] = fr_zero();
+      continue;
+    }
+    const Fr a0 = fr_add(tab[word & 255u], tab[256 + ((word >> 8) & 255u)]);
+    if (NB == 32) {
+      const Fr a1 = fr_add(tab[(word >> 16) & 255u], tab[256 + (word >> 24)]);
+      out[g] = fr_add(a0, fr_mul(x4, fr_sub(a1, a0)));
+    } else {
+      out[g] = a0;
+    }
+  }
+}
+
+// The in-word rounds of a bit sumcheck in the sound mode: messages into proof_d[0 .. 3R), x_0..x_{R-1} into fold_d, *state_d advanced (R = 5 for
+// 32-bit words, 4 for 16-bit words: *rounds_done), partial_me(u_rec, nb) into pme_d, and the table of round R (one entry per word) into t
 int fsb_sumcheck_head_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb, const Fr* u_d, uint32_t k, void* state_d, Fr* fold_d, Fr* proof_d, const Fr* u_rec_d, Fr* pme_d,
-                          DBuf<Fr>& t3) {
+                          DBuf<Fr>& t, uint32_t* rounds_done) {
   if (nb != 32 && nb != 16) return ctx->fail(ZK_ERR_ARG, "packed sumcheck: nb must be 16 or 32");
   const BytesLayout L = bytes_layout(nb);
   if (n == 0 || k != ceil_log2(n) + L.lognb) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
+  FsState* state = reinterpret_cast<FsState*>(state_d);
   const uint32_t kh = k - L.lognb;
   const uint32_t ch = kh < 10 ? kh : 10;
-  const uint32_t nbins = 2 * L.nH, ncount = nbins * BINB_LIMBS_LDS;
+  const uint32_t nbins = 2 * L.nH, ncount = nbins * BINB_LIMBS_LDS, xcount = L.nHP * BINB_LIMBS_LDS;
   ZK_ALLOC(ctx, AH, Fr, (size_t)1 << ch);
   ZK_ALLOC(ctx, BH, Fr, (size_t)1 << (kh - ch));
   ZK_ALLOC(ctx, A2, Fr, (size_t)1 << ch);
@@ -921,30 +1084,59 @@ int fsb_sumcheck_head_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t 
   const uint32_t grid = (n + BINB_WORDS_PER_WG - 1) / BINB_WORDS_PER_WG;
   ZK_ALLOC(ctx, slabs, unsigned long long, (size_t)grid * ncount);
   ZK_ALLOC(ctx, sums, unsigned long long, (size_t)ncount * 2);
+  ZK_ALLOC(ctx, xslabs, unsigned long long, (size_t)grid * xcount);
+  ZK_ALLOC(ctx, xsums, unsigned long long, (size_t)xcount * 2);
   ZK_ALLOC(ctx, v3tab, Fr, 256);
-  const size_t lds = (size_t)ncount * 8;
+  ZK_ALLOC(ctx, hfr, Fr, 1024);
+  ZK_ALLOC(ctx, tabAB, Fr, 512);
+  ZK_ALLOC(ctx, sx, Fr, 2);
+  const size_t lds = (size_t)ncount * 8, xlds = (size_t)xcount * 8 + 256 * sizeof(Fr);
   const uint64_t bytes = (uint64_t)n * (nb / 8);
+  const uint32_t* p32 = (const uint32_t*)packed;
+  const uint16_t* p16 = (const uint16_t*)packed;
+  // ---- before any challenge: the histograms
   if (nb == 32) {
     if (ctx->lds_first_use(zk::Kern<1024, &k_fsb_hist<32, uint32_t>>::desc())) {
       zk::Kern<1024, &k_fsb_hist<32, uint32_t>>::set_max_lds(lds);
       (void)hipGetLastError();
     }
-    ZK_LAUNCHB(ctx, "fs_bit_hist", bytes, 1024, (k_fsb_hist<32, uint32_t>), dim3(grid), lds, (const uint32_t*)packed, n, (const Fr*)AH.get(), (const Fr*)BH.get(), ch, (const Fr*)A2.get(),
-              (const Fr*)B2.get(), ch, slabs.get());
+    ZK_LAUNCHB(ctx, "fs_bit_hist", bytes, 1024, (k_fsb_hist<32, uint32_t>), dim3(grid), lds, p32, n, (const Fr*)AH.get(), (const Fr*)BH.get(), ch, (const Fr*)A2.get(), (const Fr*)B2.get(), ch,
+              slabs.get());
   } else {
     if (ctx->lds_first_use(zk::Kern<1024, &k_fsb_hist<16, uint16_t>>::desc())) {
       zk::Kern<1024, &k_fsb_hist<16, uint16_t>>::set_max_lds(lds);
       (void)hipGetLastError();
     }
-    ZK_LAUNCHB(ctx, "fs_bit_hist", bytes, 1024, (k_fsb_hist<16, uint16_t>), dim3(grid), lds, (const uint16_t*)packed, n, (const Fr*)AH.get(), (const Fr*)BH.get(), ch, (const Fr*)A2.get(),
-              (const Fr*)B2.get(), ch, slabs.get());
+    ZK_LAUNCHB(ctx, "fs_bit_hist", bytes, 1024, (k_fsb_hist<16, uint16_t>), dim3(grid), lds, p16, n, (const Fr*)AH.get(), (const Fr*)BH.get(), ch, (const Fr*)A2.get(), (const Fr*)B2.get(), ch,
+              slabs.get());
   }
   ZK_LAUNCHB(ctx, "binp_finish", 8ull * grid * ncount, 256, k_binb_reduce, dim3(stream_grid(ncount, 256, 32)), 0, (const unsigned long long*)slabs.get(), grid, ncount, sums.get());
-  ZK_LAUNCHB(ctx, "fs_bit_rounds", 16ull * ncount, 1024, k_fsb_rounds, dim3(1), 0, (const unsigned long long*)sums.get(), L, u_d, fold_d, reinterpret_cast<FsState*>(state_d), proof_d, pme_d,
-            v3tab.get());
-  const uint32_t n3 = n * (nb / 8);
-  if (!t3.alloc(ctx, n3)) return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: sumcheck tables");
-  ZK_LAUNCHB(ctx, "fs_bit_expand", (uint64_t)n3 + 32ull * n3, 256, k_fsb_expand, dim3(stream_grid((n3 + 3) / 4, 256, 2048)), 0, (const uint8_t*)packed, n3, (const Fr*)v3tab.get(), t3.get());
+  // ---- rounds 0, 1, 2 (one workgroup, hashing between them); leaves x_0..x_2, V3 and the normalised histogram
+  ZK_LAUNCHB(ctx, "fs_bit_rounds", 16ull * ncount, 1024, k_fsb_rounds, dim3(1), 0, (const unsigned long long*)sums.get(), L, u_d, fold_d, state, proof_d, pme_d, v3tab.get(), hfr.get());
+  // ---- round 3: the byte pairs' cross terms need V3
+  if (nb == 32) {
+    ZK_LAUNCHB(ctx, "fs_bit_hist", bytes, 1024, (k_fsb_cross<32, uint32_t>), dim3(grid), xlds, p32, n, (const Fr*)AH.get(), (const Fr*)BH.get(), ch, (const Fr*)v3tab.get(), xslabs.get());
+  } else {
+    ZK_LAUNCHB(ctx, "fs_bit_hist", bytes, 1024, (k_fsb_cross<16, uint16_t>), dim3(grid), xlds, p16, n, (const Fr*)AH.get(), (const Fr*)BH.get(), ch, (const Fr*)v3tab.get(), xslabs.get());
+  }
+  ZK_LAUNCHB(ctx, "binp_finish", 8ull * grid * xcount, 256, k_binb_reduce, dim3(stream_grid(xcount, 256, 32)), 0, (const unsigned long long*)xslabs.get(), grid, xcount, xsums.get());
+  ZK_LAUNCHB(ctx, "fs_bit_rounds", 16ull * xcount + 32ull * L.nH, 1024, k_fsb_round3, dim3(1), 0, (const Fr*)hfr.get(), (const unsigned long long*)xsums.get(), L, u_d, (const Fr*)v3tab.get(), fold_d + 3,
+            state, proof_d + 9, tabAB.get(), sx.get());
+  // ---- round 4 (32-bit words): the product of a word's two halves needs x_3
+  const uint32_t gridA = stream_grid(n, 256, 1024);
+  ZK_ALLOC(ctx, partialA, Fr, gridA);
+  if (nb == 32) {
+    ZK_LAUNCHB(ctx, "fs_bit_hist", bytes, 256, k_fsb_prodA, dim3(gridA), 0, p32, n, (const Fr*)AH.get(), (const Fr*)BH.get(), ch, (const Fr*)tabAB.get(), partialA.get());
+    ZK_LAUNCHB(ctx, "fs_bit_rounds", 32ull * (L.nH + gridA), 1024, k_fsb_round4, dim3(1), 0, (const Fr*)hfr.get(), (const Fr*)v3tab.get(), (const Fr*)(fold_d + 3), (const Fr*)sx.get(),
+              (const Fr*)partialA.get(), gridA, fold_d + 4, state, proof_d + 12);
+  }
+  // ---- the table of round R: one entry per word
+  if (!t.alloc(ctx, n)) return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: sumcheck tables");
+  if (nb == 32)
+    ZK_LAUNCHB(ctx, "fs_bit_expand", bytes + 32ull * n, 256, (k_fsb_out<32, uint32_t>), dim3(stream_grid(n, 256, 2048)), 0, p32, n, (const Fr*)tabAB.get(), (const Fr*)(fold_d + 4), t.get());
+  else
+    ZK_LAUNCHB(ctx, "fs_bit_expand", bytes + 32ull * n, 256, (k_fsb_out<16, uint16_t>), dim3(stream_grid(n, 256, 2048)), 0, p16, n, (const Fr*)tabAB.get(), (const Fr*)nullptr, t.get());
+  *rounds_done = L.R;
   return ZK_OK;
 }
 
