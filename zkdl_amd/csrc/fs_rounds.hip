@@ -16,9 +16,10 @@
 //     leaves x_r in device memory for the next launch.  No host round trip: a sumcheck is still one asynchronous chain, and the
 //     chains of different layers are still zipped by the recorder.
 //   * the last <= 10 rounds run in one workgroup with the table in LDS (k_fs_tail), one lane hashing between rounds.
-//   * the bit sumchecks of zkReLU take their rounds 0-2 from ONE weighted byte histogram of the packed words -- it depends on the weight
-//     point only, which is statement-derived -- turned into the three messages by one workgroup that hashes between them
-//     (relu_packed.hip: fsb_sumcheck_head_dev); rounds >= 3 run here on the table V3[byte].  (The throughput mode's five-round pass
+//   * the bit sumchecks of zkReLU take ALL their in-word rounds (5 / 4) from the packed words, staged by what each message needs
+//     (relu_packed.hip: fsb_sumcheck_head_dev): one weighted byte histogram that depends on the weight point only -- statement-derived
+//     -- serves rounds 0-2 (one workgroup, hashing between them); a cross-term histogram behind x_2 serves round 3; the half-word
+//     products behind x_3 serve round 4; the generic rounds here start from one entry per word.  (The throughput mode's single pass
 //     presumes x_3 and x_4 before their rounds.)
 //   * the opening's point is u_out || u_in and u_in are the inner-product sumcheck's round challenges, so the opening is recorded
 //     BEHIND the sumcheck in the same chain; its own folding uses the point's coordinates (commitment.cu:43-81), no new coins.
