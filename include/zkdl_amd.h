@@ -362,7 +362,7 @@ int zk_verify_act_open(zk_ctx* ctx, zk_gens* gens, const zk_g1j* com_d, uint32_t
 int zk_fc_prove_fs(zk_ctx* ctx, zk_fc* fc, const zk_fr* x_d, uint32_t xn, const zk_fr* z_d, uint32_t zn, zk_gens* gens, const uint8_t* seed32, uint32_t layer,
                    zk_transcript* tr);
 int zk_relu_prove_fs(zk_ctx* ctx, const zk_relu* relu, const zk_fr* x_d, const zk_fr* z_d, uint32_t n, const uint8_t* seed32, uint32_t layer, zk_transcript* tr);
-/* zk_leaky_prove (below) in this mode: zkReLU's round-by-round transcript, then the extra Hadamard sumcheck with u_lk = zk_fs_derive(seed32, layer, 1, 7, .)
+/* zk_leaky_prove (above) in this mode: zkReLU's round-by-round transcript, then the extra Hadamard sumcheck with u_lk = zk_fs_derive(seed32, layer, 1, 7, .)
  * and v_lk the hash chain which = 4. */
 int zk_leaky_prove_fs(zk_ctx* ctx, const zk_relu* relu, const zk_fr* x_d, const zk_fr* z_d, uint32_t n, const uint8_t* seed32, uint32_t layer, zk_transcript* tr);
 int zk_fs_round_challenges(const uint8_t* seed32, uint32_t layer, uint32_t kind, uint32_t which, const zk_fr* coeffs_h, uint32_t k, zk_fr* out_h);
