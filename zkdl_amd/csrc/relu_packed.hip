@@ -722,13 +722,12 @@ int binp_sumcheck_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb, 
 }
 
 // ====================================================================================================
-// Sound mode (fs_rounds.hip): the in-word rounds 0..2 of a bit sumcheck when round r's fold challenge is a hash of the messages of
-// rounds < r.  The weighted byte histogram H[p][e] = sum_{g : byte_p(g) = e} eq(u[log nb:], g) does not depend on any fold
+// Sound mode (fs_rounds.hip): the in-word rounds of a bit sumcheck when round r's fold challenge is a hash of the messages of
+// rounds < r (rounds 0..2 here, rounds 3 and 4 further down).  The weighted byte histogram H[p][e] = sum_{g : byte_p(g) = e} eq(u[log nb:], g) does not depend on any fold
 // challenge, so it is taken ONCE, before the first round; each round's three coefficient sums are then  sum_bins f_r[bin] * H[bin]
 // with factors that need only x_0 .. x_{r-1} (binb_factors' rounds 0..2) -- one workgroup computes the three messages one after the
 // other, hashing between them, and leaves x_0..x_2, the table V3[byte] (a byte's eight bits folded by them) and, from the second
-// histogram H2 (weights eq(u_rec, g)), the partial_me that follows the sumcheck.  Rounds >= 3 run on the table V3[byte_i]
-// (one entry per byte: 8x smaller than the one-element-per-bit tensor the first sound-mode prover streamed).
+// histogram H2 (weights eq(u_rec, g)), the partial_me that follows the sumcheck.
 template <int NB, class WordT>
 __device__ __forceinline__ void k_fsb_hist(uint32_t zk_nblk, const WordT* __restrict__ packed, uint32_t n, const Fr* __restrict__ AH, const Fr* __restrict__ BH, uint32_t ch,
                                                    const Fr* __restrict__ A2, const Fr* __restrict__ B2, uint32_t c2, unsigned long long* __restrict__ slabs) {
