@@ -924,11 +924,25 @@ def main():
     if "msm_accum" in prof or "msm_table_accum" in prof:
         g1_ms = sum(prof[k]["ms"] for k in prof if (k.startswith("msm_") and k != "msm_fulltable_build") or k == "g1_canonicalise") / nprof
         out["g1_msm_mops_prove"] = real_pairs / g1_ms / 1e3 if g1_ms > 0 else None   # nonzero full-width (point, scalar) pairs of one proof / its G1 kernels' time
-    if rank == 0 and not args.no_msm_probe and args.workload.startswith("mlp18m"):
-        out["g1_msm_fullwidth"] = msm_fullwidth_probe(zk, full_tables=wl.full_tables)
-        if wl.full_tables:
+    if not args.no_msm_probe and args.workload.startswith("mlp18m"):
+        # BASELINE's second metric, "G1 MSM Mop/s at 1/2/4/8 GPUs": every rank runs the same 2^24-pair probe on its own device at the same time
+        # (independent MSMs over replicated generators: the rows-of-W partitioning of SURVEY 8e, no exchange); the job figure is all ranks' pairs
+        # over the slowest rank's time
+        if world > 1:
+            dist.barrier()
+        mine = msm_fullwidth_probe(zk, full_tables=wl.full_tables)
+        out["g1_msm_fullwidth"] = mine
+        if world > 1:
+            t = torch.tensor([mine["ms"]], dtype=torch.float64, device="cuda")
+            allt = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            ms_all = [float(x.item()) for x in allt]
+            out["g1_msm_fullwidth"] = dict(mine, per_rank_ms=ms_all, ranks=world, pairs_all_ranks=mine["pairs"] * world, mops_all_ranks=mine["pairs"] * world / max(ms_all) / 1e3)
+            out["g1_msm_mops"] = out["g1_msm_fullwidth"]["mops_all_ranks"]
+        else:
+            out["g1_msm_mops"] = mine["mops"]
+        if wl.full_tables and rank == 0 and world == 1:
             out["g1_msm_fullwidth_bucket_method"] = msm_fullwidth_probe(zk, full_tables=0)
-        out["g1_msm_mops"] = out["g1_msm_fullwidth"]["mops"]
     if world > 1:
         dist.barrier()
     rc = 0
