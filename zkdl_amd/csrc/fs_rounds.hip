@@ -82,7 +82,7 @@ __device__ __forceinline__ Fr fs_cur_elem(const Fr* __restrict__ prev, uint32_t 
 template <int MODE>
 __device__ __forceinline__ void k_fs_round(uint32_t zk_nblk, const Fr* __restrict__ a_prev, const Fr* __restrict__ b_prev, Fr* __restrict__ a_cur, Fr* __restrict__ b_cur,
                                             const Fr* __restrict__ fold_prev, const Fr* __restrict__ A, uint32_t c, const Fr* __restrict__ B, uint32_t prev_size,
-                                            uint32_t cur_size, uint32_t npairs, Fr* __restrict__ partial) {
+                                            uint32_t cur_size, uint32_t npairs, Fr* __restrict__ partial, uint32_t b_is_bits) {
   __shared__ Fr lds[12];
   const bool first = fold_prev == nullptr;
   const Fr x = first ? fr_zero() : *fold_prev;
@@ -114,9 +114,17 @@ __device__ __forceinline__ void k_fs_round(uint32_t zk_nblk, const Fr* __restric
       if (MODE == FSC_HP) {
         const Fr w = fr_mul(A[g & mask], B[g >> c]);
         const Fr a0w = fr_mul(a0, w), daw = fr_mul(da, w);
-        c0 = fr_mul(a0w, b0);                     // proof.cu:110-137
-        c2 = fr_mul(daw, db);
-        c1 = fr_sub(fr_sub(fr_mul(fr_add(a0w, daw), b1), c0), c2);
+        if (first && b_is_bits) {
+          // round 0 of zkReLU's Hadamard sumchecks: the second operand is a 0 / 1 tensor (sign, 1 - sign), so its three products are selections
+          const bool z0 = l_is_zero(b0), z1 = l_is_zero(b1);
+          c0 = z0 ? fr_zero() : a0w;
+          c2 = z0 == z1 ? fr_zero() : (z1 ? fr_neg(daw) : daw);
+          c1 = fr_sub(fr_sub(z1 ? fr_zero() : fr_add(a0w, daw), c0), c2);
+        } else {
+          c0 = fr_mul(a0w, b0);                     // proof.cu:110-137
+          c2 = fr_mul(daw, db);
+          c1 = fr_sub(fr_sub(fr_mul(fr_add(a0w, daw), b1), c0), c2);
+        }
       } else {
         c0 = fr_mul(a0, b0);                      // proof.cu:55-70
         c2 = fr_mul(da, db);
@@ -245,7 +253,8 @@ __device__ __forceinline__ void k_fs_tail(uint32_t zk_nblk, const Fr* __restrict
 
 // fold_d: k slots the round challenges are WRITTEN to; weight_d: the eq point (static), nullptr for the inner-product form
 template <int MODE>
-static int run_sumcheck_fs(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n, FsState* state_d, Fr* fold_d, const Fr* weight_d, uint32_t k, Fr* proof_d) {
+static int run_sumcheck_fs(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n, FsState* state_d, Fr* fold_d, const Fr* weight_d, uint32_t k, Fr* proof_d,
+                           bool b_is_bits = false) {
   const bool two = MODE != FSC_BIN;
   std::vector<uint32_t> sizes(k + 2);
   sizes[0] = n;
@@ -281,7 +290,7 @@ static int run_sumcheck_fs(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t
     const Fr* A = MODE != FSC_IP ? tabA.get() + ((1u << s) - (1u << (s - r))) : nullptr;
     const uint64_t bytes = (two ? 2ull : 1ull) * 32ull * ((uint64_t)prev_size + (r ? cur_size : 0));
     ZK_LAUNCHB(ctx, tag, bytes, 256, k_fs_round<MODE>, dim3(grid), 0, a_prev, b_prev, ac, bc, (const Fr*)(r ? fold_d + (r - 1) : nullptr), A, c, (const Fr*)tabB.get(), prev_size,
-               cur_size, npairs, part);
+               cur_size, npairs, part, b_is_bits ? 1u : 0u);
     ZK_LAUNCHB(ctx, "fs_hash", 96ull * grid, 256, k_fs_hash, dim3(1), 0, (const Fr*)part, grid, proof_d + 3 * r, state_d, fold_d + r);
     if (r > 0) {
       a_prev = ac;
@@ -455,7 +464,7 @@ static int relu_prove_fs_body(zk_ctx* ctx, const zk_relu* relu, const Fr* x, uin
   }
   rec_split(ctx, REC_GROUP_FC_OPEN);
   if (k > 0 && n <= (1u << (k - 1))) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions 3");
-  ZK_TRY(run_sumcheck_fs<FSC_HP>(ctx, x, relu->sign, n, states + 2, c + offs[6], c + offs[5], k, out));
+  ZK_TRY(run_sumcheck_fs<FSC_HP>(ctx, x, relu->sign, n, states + 2, c + offs[6], c + offs[5], k, out, true));
   return ZK_OK;
 }
 int relu_prove_fs(zk_ctx* ctx, const zk_relu* relu, const Fr* x, uint32_t n, const uint8_t* seed32, uint32_t layer, zk_transcript* tr) {
@@ -485,7 +494,7 @@ int leaky_prove_fs(zk_ctx* ctx, const zk_relu* relu, const Fr* x, uint32_t n, co
     DBuf<Fr> chd;
     ZK_TRY(upload_fr(ctx, chd, ch.data(), (uint32_t)ch.size()));
     Fr* c = chd.get();
-    return run_sumcheck_fs<FSC_HP>(ctx, relu->low, relu->nsign, n, reinterpret_cast<FsState*>(c + 2 * k), c + k, c, k, out);
+    return run_sumcheck_fs<FSC_HP>(ctx, relu->low, relu->nsign, n, reinterpret_cast<FsState*>(c + 2 * k), c + k, c, k, out, true);
   };
   return guard.finish(body());
 }
