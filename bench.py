@@ -398,6 +398,86 @@ def run_sharded(args, zk, dims, batch, rank, world, dist):
     zk.close()
 
 
+LINE_LIMIT = 4096           # the driver keeps an 8 KB tail of stdout and parses its last line: the line has to fit with room to spare (BENCH_r03 did not)
+
+
+def _r(x, sig=6):
+    """floats to `sig` significant digits (the line is read by people and a parser; 17-digit doubles are just bytes)"""
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x))
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def compact_line(out):
+    """The ONE stdout line: the contract's keys, `roofline` + `cpu_baseline` + `parity_checked`, and the handful of scalars a reader wants
+    next to the headline.  Everything else (roofline_all, per-family kernel table, PMC blocks, extensions, the latency / steady-state
+    breakdowns, the G1 model, setup times) goes to the detail file."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: out[k] for k in keep}
+    cfg = out["config"]
+    line["config"] = {k: cfg[k] for k in ("workload", "dims", "batch_per_gpu", "parallelism", "msm", "derive_rounds", "inflight", "g1_batch", "g1_streams",
+                                          "full_table_window_bits", "drain_form_proofs", "prewarm_process") if k in cfg}
+    r = out.get("roofline") or {}
+    line["roofline"] = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_per_step", "alg_macs_per_launch")}
+    if r.get("hbm"):
+        line["roofline"]["hbm"] = {k: r["hbm"].get(k) for k in ("achieved", "peak", "unit", "frac")}
+    if r.get("pmc_file"):
+        line["roofline"]["traffic_source"] = r["pmc_file"]
+        line["roofline"]["traffic_stale"] = r.get("traffic_stale")
+    rf = out.get("roofline_chip_filling")
+    if rf:
+        line["roofline_chip_filling"] = {k: rf.get(k) for k in ("kernel", "frac", "avg_launch_ms", "launches_per_step")}
+    c = out.get("cpu_baseline")
+    if c:
+        line["cpu_baseline"] = {k: c.get(k) for k in ("value", "unit", "cores", "kind", "sample", "extrapolated", "ms_per_proof")}
+    p = out.get("parity_checked")
+    if p:
+        line["parity_checked"] = {"ok": p["ok"], "fr": p["fr"], "g1": p["g1"], "calls": len(p["calls"]), "mismatch": p["mismatch"][:4]}
+    for k in ("latency_ms_per_proof", "steady_state_ms_per_proof", "g1_msm_mops", "g1_msm_mops_commit", "collective_world_size", "collective_backend",
+              "per_rank_ms_per_proof", "aggregate_fr", "host_enqueue_ms_per_step"):
+        if out.get(k) is not None:
+            line[k] = out[k]
+    bm = out.get("g1_msm_fullwidth_bucket_method")
+    if bm:
+        line["g1_msm_mops_bucket_method"] = bm["mops"]
+    ext = out.get("extensions") or {}
+    for k, short in (("sound_mode_round_by_round_fiat_shamir", "sound_mode_ms_per_proof"), ("activation_openings_in_proof", "act_openings_ms_per_proof")):
+        if k in ext:
+            line[short] = ext[k]["steady_state_ms_per_proof"]
+    line["value_is"] = "pipelined throughput: wall of K proofs / K / batch; latency_ms_per_proof = ONE synchronous prove loop (demo.cu:124-140)"
+    line["detail"] = out.get("detail_file")
+    return _r(line)
+
+
+def emit(out, detail_path):
+    """Write the full record to `detail_path` and print the compact line (and nothing else) on stdout."""
+    if detail_path:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(detail_path)), exist_ok=True)
+            with open(detail_path, "w") as f:
+                json.dump(out, f, indent=1)
+            out["detail_file"] = os.path.relpath(detail_path, ROOT) if os.path.abspath(detail_path).startswith(ROOT) else detail_path
+        except OSError as e:                                 # a read-only tree must not cost the headline
+            sys.stderr.write("bench.py: could not write %s: %s\n" % (detail_path, e))
+            out["detail_file"] = None
+    line = compact_line(out)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:                                  # never again: shed the optional keys, then the sample text
+        for k in ("value_is", "per_rank_ms_per_proof", "roofline_chip_filling", "host_enqueue_ms_per_step", "aggregate_fr"):
+            line.pop(k, None)
+        if "cpu_baseline" in line and isinstance(line["cpu_baseline"].get("sample"), str):
+            line["cpu_baseline"]["sample"] = line["cpu_baseline"]["sample"][:160]
+        line["config"].pop("dims", None)
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < LINE_LIMIT, "bench line of %d bytes" % len(text)
+    print(text)
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -436,6 +516,8 @@ def main():
                     help="independent (default, the bench contract): every rank proves its own batches, one all-reduce of the run aggregate; "
                          "shard: the N ranks prove ONE batch together, sharded by batch rows (zkdl_amd/shard.py: strong scaling of a single proof, "
                          "two small all-gathers per proof, synchronous orchestration -- a functional mode, not the headline)")
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "bench_detail.json"), help="where the full record goes (roofline_all, per-family kernel table, PMC blocks, extensions, "
+                    "latency / steady-state breakdowns); stdout carries ONE compact JSON line (< 4 KB); empty = do not write")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the throw-away process that initialises torch on the GPU before this one does (see below)")
     ap.add_argument("--launcher-selftest", type=int, default=None, metavar="FAIL_RANK",
                     help="CPU-only check of the N-rank launch path (tests/test_dist_aggregate.py): gloo all-reduce of per-rank digests, no GPU work; "
@@ -835,8 +917,15 @@ def main():
             macs_per_step["msm_derive"] = n_derived * (2 * (128 * JDBL + 32 * JADD + JDBL + 6 * JADD) + JADD + JADD) * FP_MACS
         if "g1_canonicalise" in prof:
             macs_per_step["g1_canonicalise"] = n_g1_out * (INV + 5) * FP_MACS         # 1/Z, Z^-2, Z^-3, x, y
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_r03.json")
-    pmc_all = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
+    # the newest counter summary under profiles/ (tools/collect_profiles.sh + tools/pmc_summary.py: separate rocprofv3 --pmc passes of this bench).
+    # It records the fingerprint of the sources it was collected from; if this tree differs, the traffic figure is flagged stale.
+    import glob as _glob
+    from src_fingerprint import source_fingerprint
+    pmc_files = sorted(_glob.glob(os.path.join(ROOT, "profiles", "pmc_r[0-9][0-9].json")))
+    pmc_path = pmc_files[-1] if pmc_files else None
+    pmc_all = json.load(open(pmc_path)) if pmc_path else {}
+    pmc_name = ("profiles/" + os.path.basename(pmc_path)) if pmc_path else None
+    pmc_stale = bool(pmc_all) and pmc_all.get("src_sha256") != source_fingerprint()
 
     def pmc_of(family):
         want = fam[family][0] if family in fam else [family]
@@ -878,7 +967,8 @@ def main():
                 "hbm": {"achieved": hbm_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_ach / HBM_PEAK_GBPS, "alg_bytes_per_launch": pv["bytes"] / launches,
                         "traffic_bytes_per_launch": traffic},
                 "pmc": ({kk: hit[kk] for kk in hit if kk not in ("fetch_kb_per_launch", "write_kb_per_launch")} if hit else None),
-                "pmc_source": (("profiles/pmc_r03.json, collected at commit %s: a separate rocprofv3 --pmc run of this bench, not this run" % pmc_all.get("commit", "?")) if hit else None)}
+                "pmc_source": (("%s, collected at commit %s: a separate rocprofv3 --pmc run of this bench, not this run" % (pmc_name, pmc_all.get("commit", "?"))) if hit else None),
+                "pmc_file": (pmc_name if hit else None), "traffic_stale": (pmc_stale if hit else None)}
 
     modelled = [k for k in kernels if k in macs_per_step and prof[k]["ms"] > 0]
     roofline_all = [roofline_of(k) for k in modelled]
@@ -954,8 +1044,7 @@ def main():
             if not checked["ok"]:
                 rc = 4
     if rank == 0:
-        print(json.dumps(out))
-        sys.stdout.flush()
+        emit(out, args.detail_out)
     if world > 1:
         dist.destroy_process_group()
     zk.close()

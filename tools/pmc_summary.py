@@ -19,7 +19,7 @@ import sys
 
 def main():
     root = sys.argv[1]
-    out_path = sys.argv[2] if len(sys.argv) > 2 else "profiles/pmc_r03.json"
+    out_path = sys.argv[2] if len(sys.argv) > 2 else "profiles/pmc_r04.json"
     commit = sys.argv[3] if len(sys.argv) > 3 else "unknown"
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
     for path in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
@@ -46,7 +46,9 @@ def main():
         if rec.get("SQ_BUSY_CYCLES"):
             rec["valu_active_per_busy_cycle"] = rec.get("SQ_ACTIVE_INST_VALU", 0.0) / rec["SQ_BUSY_CYCLES"]
         kernels[k] = rec
-    json.dump({"source": "rocprofv3 --pmc passes of `bench.py --serial --steps 2 --warmup 1` (tools/collect_profiles.sh), averaged per launch",
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from src_fingerprint import source_fingerprint
+    json.dump({"src_sha256": source_fingerprint(), "source": "rocprofv3 --pmc passes of `bench.py --serial --steps 2 --warmup 1` (tools/collect_profiles.sh), averaged per launch",
                "commit": commit, "kernels": kernels}, open(out_path, "w"), indent=1, sort_keys=True)
     print("wrote", out_path, len(kernels), "kernels")
 
