@@ -779,7 +779,7 @@ def main():
         coms_ = [fc.com() for fc in wl.fcs]
         seed_ = statement_digest(zk, dims, batch, wl.gens, coms_, wl.X, wl.Yhat)
         chal_ = fs_challenges(seed_, dims, batch)
-        pts_, ac_ = act_claim_points(dims, chal_), act_open_challenges(seed_, dims, batch)
+        pts_, ac_ = act_claim_points(dims, chal_), act_open_challenges(seed_, dims, batch)   # timing only: no activation commitments are made here, so the seed does not absorb them
 
         def run_ext(n, which):
             zk.sync()

@@ -152,7 +152,7 @@ int zk_set_msm_window(zk_ctx* ctx, uint32_t window_bits);   /* 0 = automatic */
  *   "lanes"         worker streams (the recorder's groups, the G1 streams of zk_transcript_seal); off = one stream
  *   "g1_batch"      (default 1) the G1 phases of that many consecutively sealed proofs run as ONE batch (one MSM batch, one derivation,
  *                   one canonicalisation): the latency-bound launches behind the accumulation are shared; a sealed proof then waits for
- *                   its partners (or for anyone touching its transcript, or zk_ctx_sync).  Throughput configuration of bench.py: 2.
+ *                   its partners (or for anyone touching its transcript, or zk_ctx_sync).  Throughput configuration of bench.py and zkdl::ProofPipeline: 3.
  *   "g1_mask"       (default 1) sealed proofs' G1 phases run on streams confined to every other compute unit, so that the chip-filling accumulation
  *                   leaves room for the next proofs' Fr chains; 0 = an unmasked stream: what a single proof with nothing in flight wants (latency)
  *   "g1_streams"    (default 0 = all) how many of the context's G1 streams sealed proofs rotate over
@@ -338,6 +338,13 @@ int zk_sha256(const void* data, size_t len, uint8_t* out32);
  * holds the tensor, and the generators' window tables exist).  One sumcheck and one opening per hidden layer instead of three openings. */
 int zk_act_open(zk_ctx* ctx, zk_gens* gens, const zk_fr* z_d, const zk_fr* a_d, uint32_t n, const zk_fr* pts_h, const zk_fr* alpha_h, const zk_fr* fold_h,
                 zk_transcript* tr);
+/* The same with the reduction's challenges bound to the prover's messages (the sound mode of the layer proofs, zk_*_prove_fs): alpha =
+ * zk_fs_derive(seed32, layer, 2, 0, 1) and every ROUND challenge -- hence the opening point r' -- is the hash chain of zk_fs_round_challenges with
+ * kind = 2, which = 0 over the reduction's own round messages, computed on the device.  seed32 must absorb everything alpha may depend on: the
+ * statement, the activation commitments, the three claimed evaluations and their points (zkdl_amd/proof.py: act_layer_seed).  Same transcript layout;
+ * the verifier re-derives alpha and fold and calls zk_verify_act_open. */
+int zk_act_open_fs(zk_ctx* ctx, zk_gens* gens, const zk_fr* z_d, const zk_fr* a_d, uint32_t n, const zk_fr* pts_h, const uint8_t* seed32, uint32_t layer,
+                   zk_transcript* tr);
 /* The verifier's side: com_d = the 2m points [com(Z_i) ; com(A_i)] (device), y_h = the three claimed evaluations as the layer proofs state them,
  * fr_h / g1_h / inf_h the slice zk_act_open appended (G1 affine-canonical).  Checks the sumcheck, E~(r') (public arithmetic), T~(r') == t(0), and the
  * opening with the checks of zk_verify_open. */
@@ -358,7 +365,8 @@ int zk_verify_act_open(zk_ctx* ctx, zk_gens* gens, const zk_g1j* com_d, uint32_t
  * the sumcheck, so it is proved behind it.  seed32: a digest of the public statement (zkdl_amd/proof.py: statement_digest).  The transcript
  * has the layout of zk_fc_prove / zk_relu_prove; zk_fs_round_challenges re-derives the round challenges from it (coeffs_h: the k coefficient
  * triples), after which zk_verify_fc / zk_verify_relu check the proof as before.  Fed the derived challenges, zk_fc_prove / zk_relu_prove
- * (and the CPU oracle) produce the same transcript bit for bit. */
+ * (and the CPU oracle) produce the same transcript bit for bit.  Coefficients are hashed as stored, so only canonical encodings (< r) are accepted:
+ * zk_fs_round_challenges returns ZK_ERR_RANGE otherwise, and every zk_verify_* rejects a proof holding a field element >= r. */
 int zk_fc_prove_fs(zk_ctx* ctx, zk_fc* fc, const zk_fr* x_d, uint32_t xn, const zk_fr* z_d, uint32_t zn, zk_gens* gens, const uint8_t* seed32, uint32_t layer,
                    zk_transcript* tr);
 int zk_relu_prove_fs(zk_ctx* ctx, const zk_relu* relu, const zk_fr* x_d, const zk_fr* z_d, uint32_t n, const uint8_t* seed32, uint32_t layer, zk_transcript* tr);

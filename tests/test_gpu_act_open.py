@@ -35,7 +35,7 @@ def test_activation_openings_inside_the_proof(zk, oracle, dims, batch, derive):
     import bigint_model as bm
     from mlp_util import enqueue_proof, setup_mlp_gpu, synth_mlp
     from zkdl_amd.capi import Transcript
-    from zkdl_amd.proof import (act_open_lengths, fs_challenges, parse_transcript, prove_activation_openings, statement_digest, verify_mlp,
+    from zkdl_amd.proof import (act_open_lengths, act_statement_seed, fs_challenges, parse_transcript, prove_activation_openings, statement_digest, verify_mlp,
                                 verify_mlp_with_activation_openings)
     model = synth_mlp(oracle, dims, batch, seed=51)
     st = setup_mlp_gpu(zk, model)
@@ -43,17 +43,18 @@ def test_activation_openings_inside_the_proof(zk, oracle, dims, batch, derive):
     seed = statement_digest(zk, dims, batch, st["gens"], coms, st["X"], st["Yhat"])
     chal = fs_challenges(seed, dims, batch)
     act_coms = concat_coms(zk, st["gens"], st["Z"], st["A"])
+    aseed = act_statement_seed(zk, seed, act_coms)         # the openings' challenges depend on the activation commitments too
     zk.set_flag("derive_rounds", derive)
     try:
         tr = Transcript(zk)
         enqueue_proof(st, chal, tr)
         base_counts = None
-        prove_activation_openings(zk, dims, batch, st["gens"], st["Z"], st["A"], chal, seed, tr)
+        prove_activation_openings(zk, dims, batch, st["gens"], st["Z"], st["A"], chal, aseed, tr)
         blob = tr.serialize()
         # the same through a sealed (pipelined) submission
         tr2 = Transcript(zk)
         enqueue_proof(st, chal, tr2)
-        prove_activation_openings(zk, dims, batch, st["gens"], st["Z"], st["A"], chal, seed, tr2)
+        prove_activation_openings(zk, dims, batch, st["gens"], st["Z"], st["A"], chal, aseed, tr2)
         tr2.seal()
         assert tr2.serialize() == blob
     finally:
@@ -69,7 +70,7 @@ def test_activation_openings_inside_the_proof(zk, oracle, dims, batch, derive):
     # the opened value IS the random combination of the two tensors at the reduction's point (big-integer model on the downloaded tensors)
     from zkdl_amd.proof import act_open_challenges
     off = fr.shape[0] - nf_act
-    for i, (alpha, fold) in enumerate(act_open_challenges(seed, dims, batch)):
+    for i, (alpha, fold) in enumerate(act_open_challenges(aseed, dims, batch)):
         nf = lens[i][0]
         t0 = bm.fr_from_mont(fr[off + nf - 1])
         r = [bm.fr_from_mont(x) for x in fold]
@@ -104,7 +105,7 @@ def test_activation_openings_at_full_size(zk):
     import time
     import bench
     from zkdl_amd.capi import Transcript
-    from zkdl_amd.proof import fs_challenges, prove_activation_openings, statement_digest, verify_mlp_with_activation_openings
+    from zkdl_amd.proof import act_statement_seed, fs_challenges, prove_activation_openings, statement_digest, verify_mlp_with_activation_openings
     dims, batch = bench.WORKLOADS["mlp18m_b256"]
     wl = bench.Workload(zk, dims, batch, seed=21)
     coms = [fc.com() for fc in wl.fcs]
@@ -115,6 +116,7 @@ def test_activation_openings_at_full_size(zk):
     act_coms = concat_coms(zk, wl.gens[:-1], wl.Z, wl.A)
     zk.sync()
     t_commit = (time.perf_counter() - t0) * 1e3
+    aseed = act_statement_seed(zk, seed, act_coms)
     zk.set_flag("derive_rounds", 1)
     try:
         tr = Transcript(zk)
@@ -125,7 +127,7 @@ def test_activation_openings_at_full_size(zk):
             for rep in range(3):
                 wl.prove(chal, tr)
                 if with_act:
-                    prove_activation_openings(zk, dims, batch, wl.gens, wl.Z, wl.A, chal, seed, tr)
+                    prove_activation_openings(zk, dims, batch, wl.gens, wl.Z, wl.A, chal, aseed, tr)
                 tr.flush()
             zk.sync()
             times[with_act] = (time.perf_counter() - t0) * 1e3 / 3
@@ -140,4 +142,83 @@ def test_activation_openings_at_full_size(zk):
     bad = bytearray(blob)
     bad[-200] ^= 1
     assert not verify_mlp_with_activation_openings(zk, dims, batch, wl.gens, coms, act_coms, wl.X, wl.Yhat, bytes(bad), chal=chal)[0]
+    tr.close()
+
+
+@pytest.mark.parametrize("dims,batch", [([16, 32, 24, 8], 4), ([40, 70, 30], 20), ([600, 900, 700, 300], 64)])
+def test_sound_layer_proofs_with_hashed_activation_openings(zk, oracle, dims, batch):
+    """(i) the openings' challenges must not be known before com(Z_i), com(A_i) are fixed -- they are derived from a seed that absorbs the
+    activation commitments; (ii) in the sound mode alpha depends on the claimed evaluations and the reduction's round challenges on its own round
+    messages (zk_act_open_fs: the hash runs on the device); (iii) a sealed transcript that mixes sound-mode layer proofs (their openings sit in a
+    chain that is NOT early) with activation openings (an early chain) must not start its G1 phase behind the early chains only."""
+    from mlp_util import setup_mlp_gpu, synth_mlp
+    from zkdl_amd.capi import Transcript
+    from zkdl_amd.proof import (act_open_lengths, act_statement_seed, fs_round_mode_challenges, parse_transcript, prove_activation_openings,
+                                prove_activation_openings_fs, prove_mlp_fs, statement_digest, verify_mlp_with_activation_openings)
+    model = synth_mlp(oracle, dims, batch, seed=77)
+    st = setup_mlp_gpu(zk, model)
+    coms = [fc.com() for fc in st["fcs"]]
+    seed = statement_digest(zk, dims, batch, st["gens"], coms, st["X"], st["Yhat"])
+    act_coms = concat_coms(zk, st["gens"], st["Z"], st["A"])
+    aseed = act_statement_seed(zk, seed, act_coms)
+    args = (zk, dims, batch, st["gens"], coms, act_coms, st["X"], st["Yhat"])
+    tr = Transcript(zk)
+    prove_mlp_fs(st["fcs"], st["relus"], st["gens"], st["X"], st["Z"], st["A"], st["Yhat"], seed, tr)
+    prove_activation_openings_fs(zk, dims, batch, st["gens"], st["Z"], st["A"], seed, aseed, tr)
+    blob = tr.serialize()
+    ok, msg, remaining = verify_mlp_with_activation_openings(*args, blob, sound=True)
+    assert ok, msg
+    assert len(remaining) == 4 * (len(dims) - 2)
+    # the statement-derived schedule does not verify this proof, and other activation commitments change every challenge
+    assert not verify_mlp_with_activation_openings(*args, blob, sound=False)[0]
+    fr, aff, inf = parse_transcript(blob)
+    lens = act_open_lengths(dims, batch)
+    nf_act = sum(a for a, _ in lens)
+    rng = np.random.default_rng(9)
+    for idx in list(range(fr.shape[0] - nf_act, fr.shape[0], 2)) + [3, fr.shape[0] - nf_act - 2]:
+        bad = bytearray(blob)
+        bad[24 + 32 * idx + int(rng.integers(0, 31))] ^= 1 << int(rng.integers(0, 8))
+        assert not verify_mlp_with_activation_openings(*args, bytes(bad), sound=True)[0], idx
+    # adaptive tampering of a reduction's round message: c0 + d, c1 - 2d keeps that round's own check; the challenges derived from it change
+    import bigint_model as bm
+    off = fr.shape[0] - nf_act
+    d = 12345
+    c0, c1 = bm.limbs_to_int(fr[off]), bm.limbs_to_int(fr[off + 1])
+    bad = bytearray(blob)
+    bad[24 + 32 * off:24 + 32 * off + 32] = np.array(bm.int_to_limbs((c0 + d) % bm.R_MOD, 8), dtype=np.uint32).tobytes()
+    bad[24 + 32 * (off + 1):24 + 32 * (off + 1) + 32] = np.array(bm.int_to_limbs((c1 - 2 * d) % bm.R_MOD, 8), dtype=np.uint32).tobytes()
+    assert not verify_mlp_with_activation_openings(*args, bytes(bad), sound=True)[0]
+    # a non-canonical encoding (c + r, same field element) of a proof value is refused outright
+    small = [i for i in range(fr.shape[0]) if bm.limbs_to_int(fr[i]) + bm.R_MOD < (1 << 256)]
+    if small:
+        i0 = small[-1]
+        bad = bytearray(blob)
+        bad[24 + 32 * i0:24 + 32 * i0 + 32] = np.array(bm.int_to_limbs(bm.limbs_to_int(fr[i0]) + bm.R_MOD, 8), dtype=np.uint32).tobytes()
+        assert not verify_mlp_with_activation_openings(*args, bytes(bad), sound=True)[0]
+    # (iii) sound layer proofs + statement-scheduled activation openings, SEALED (pipelined submission, batched G1 phases) == the same recorded synchronously
+    chal = None
+    blobs = []
+    for sealed in (False, True):
+        zk.set_flag("g1_batch", 2 if sealed else 1)
+        try:
+            trs = [Transcript(zk) for _ in range(3)]
+            for t in trs:
+                prove_mlp_fs(st["fcs"], st["relus"], st["gens"], st["X"], st["Z"], st["A"], st["Yhat"], seed, t)
+                if chal is None:
+                    t.flush()
+                    chal = fs_round_mode_challenges(seed, dims, batch, t.read()[0])
+                    prove_mlp_fs(st["fcs"], st["relus"], st["gens"], st["X"], st["Z"], st["A"], st["Yhat"], seed, t)
+                prove_activation_openings(zk, dims, batch, st["gens"], st["Z"], st["A"], chal, aseed, t)
+                if sealed:
+                    t.seal()
+                else:
+                    t.flush()
+            blobs.append([t.serialize() for t in trs])
+            for t in trs:
+                t.close()
+        finally:
+            zk.set_flag("g1_batch", 1)
+    assert blobs[0] == blobs[1] and blobs[0][0] == blobs[0][2]
+    ok, msg, _ = verify_mlp_with_activation_openings(*args, blobs[1][1], chal=chal)
+    assert ok, msg
     tr.close()

@@ -297,3 +297,37 @@ def test_demo_aggregates_over_rccl_without_torch(tmp_path):
     digest = run.stdout.split("digest ")[1].split()[0]
     line = [ln for ln in run.stdout.splitlines() if ln.startswith("Aggregate over 1 ranks")]
     assert line and line[0].split(": ")[-1].strip() == digest
+
+
+def test_demo_pipeline_reproduces_the_bench_headline_without_python(tmp_path):
+    """north_star: "C++ host code calling hand-written HIP kernels through a thin C-ABI".  `demo --pipeline K` is bench.py's timed loop in C++
+    (zkdl::ProofPipeline: rotating sealed transcripts, batched G1 phases, derived round commitments, drain form, digests summed on the device):
+    on the statement bench.py times (`python -m zkdl_amd.model --like-bench 0`, generator seed 0xC0FFEE, step k's challenges from the same
+    per-step seed) it must give the SAME run aggregate as bench.py -- every Fr and G1 transcript value of all K proofs enters it -- at the
+    same time per proof (the C++ loop has less host work per proof, so it may only be faster; 10 % slack for box noise)."""
+    exe = os.path.join(HOST, "demo")
+    if not os.path.exists(exe):
+        pytest.skip("zkdl_amd/host/demo not built (needs LibTorch)")
+    import json
+    import re
+    d = str(tmp_path)
+    K = 20
+    subprocess.run([sys.executable, "-m", "zkdl_amd.model", "--like-bench", "0", "--out-dir", d], check=True, cwd=ROOT)
+    run = subprocess.run([exe, os.path.join(d, "traced_model.pt"), os.path.join(d, "sample_input.pt"), "--seed", str(0xC0FFEE), "--full-tables", "12",
+                          "--pipeline", str(K), "--warmup", "5"], capture_output=True, text=True, cwd=d, timeout=900)
+    assert run.returncode == 0, run.stdout + run.stderr
+    ms_cpp = float(re.search(r"Pipelined proof time: .*?, ([0-9.eE+-]+) ms per batch-256 proof", run.stdout).group(1))
+    agg_cpp = int(re.search(r"Run aggregate: (0x[0-9a-f]+)", run.stdout).group(1), 16)
+    bench = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", str(K), "--warmup", "5", "--no-cpu-baseline", "--steady-steps", "0",
+                            "--latency-reps", "0", "--ext-steps", "0", "--no-msm-probe", "--no-prewarm", "--detail-out", os.path.join(d, "detail.json")],
+                           capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert bench.returncode == 0, bench.stderr[-2000:]
+    line = json.loads(bench.stdout.strip().splitlines()[-1])
+    assert int(line["aggregate_fr"], 16) == agg_cpp                 # the same 20 proofs, value for value
+    assert 0 < ms_cpp < 1.10 * line["ms_per_step"]
+    assert ms_cpp / 256 < 100.0                                     # north_star: <= 0.1 s per example
+    keep = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(keep):
+        with open(os.path.join(keep, "demo_pipeline.txt"), "w") as f:
+            f.write("$ python -m zkdl_amd.model --like-bench 0 && ./demo traced_model.pt sample_input.pt --seed 0xC0FFEE --full-tables 12 --pipeline %d --warmup 5\n" % K + run.stdout)
+            f.write("\n$ python bench.py --steps %d --warmup 5 (side measurements off): ms_per_step %.4f, aggregate_fr %s\n" % (K, line["ms_per_step"], line["aggregate_fr"]))

@@ -83,7 +83,10 @@ static int open_known_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, uint32_t tn, con
 }
 
 // pts_h = p1 | p2 | p3 (k challenges each), fold_h: the k + 1 round challenges.  Appends Fr: [sumcheck 3 (k + 1) + 2][t(0)], G1: [com(u_hi)][3 k_lo + 1].
-static int act_open_body(zk_ctx* ctx, zk_gens* gens, const Fr* z, const Fr* a, uint32_t n, const zk_fr* pts_h, const zk_fr* alpha_h, const zk_fr* fold_h, zk_transcript* tr) {
+// fs_seed32 != nullptr (zk_act_open_fs): alpha = zk_fs_derive(fs_seed32, layer, 2, 0) and every ROUND challenge of the reduction -- hence the opening
+// point r' -- is a hash of the rounds before it, computed on the device (fs_rounds.hip); alpha_h / fold_h are then ignored.
+static int act_open_body(zk_ctx* ctx, zk_gens* gens, const Fr* z, const Fr* a, uint32_t n, const zk_fr* pts_h, const zk_fr* alpha_h, const zk_fr* fold_h, zk_transcript* tr,
+                         const uint8_t* fs_seed32 = nullptr, uint32_t layer = 0) {
   const uint32_t n_gens = gens->n;
   const uint32_t k = ceil_log2(n);
   if (n == 0 || n != (1u << k) || k + 1 > 31 || (2ull * n) % n_gens) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
@@ -101,13 +104,20 @@ static int act_open_body(zk_ctx* ctx, zk_gens* gens, const Fr* z, const Fr* a, u
   // starts behind the early chains only (layers.hip: g1_phase_run)
   rec_split(ctx, REC_GROUP_FC_OPEN, /*early=*/true);
   LaneScope lane(ctx, recording.on ? ~0u : 0u);
-  // [p1 | p2 | p3 | fold]
-  std::vector<zk_fr> ch(3 * (size_t)k + k + 1);
+  // [p1 | p2 | p3 | fold | hash state (sound mode)]
+  std::vector<zk_fr> ch(3 * (size_t)k + k + 1 + (fs_seed32 ? 1 : 0), zk_fr{});
   for (size_t i = 0; i < 3 * (size_t)k; i++) ch[i] = pts_h[i];
-  for (uint32_t i = 0; i <= k; i++) ch[3 * (size_t)k + i] = fold_h[i];
+  zk_fr alpha_fs;
+  if (fs_seed32) {
+    ZK_TRY(zk_fs_derive(fs_seed32, layer, 2, 0, 1, &alpha_fs));
+    alpha_h = &alpha_fs;
+    fs_state0_slot(fs_seed32, layer, 2, 0, &ch[3 * (size_t)k + k + 1]);
+  } else {
+    for (uint32_t i = 0; i <= k; i++) ch[3 * (size_t)k + i] = fold_h[i];
+  }
   DBuf<Fr> chd;
   ZK_TRY(upload_fr(ctx, chd, ch.data(), (uint32_t)ch.size()));
-  const Fr* fold_d = chd.get() + 3 * (size_t)k;
+  Fr* fold_d = chd.get() + 3 * (size_t)k;
   const uint32_t c = k < 10 ? k : 10;
   ZK_ALLOC(ctx, lo, Fr, (size_t)3 << c);
   ZK_ALLOC(ctx, hi, Fr, (size_t)3 << (k - c));
@@ -120,7 +130,8 @@ static int act_open_body(zk_ctx* ctx, zk_gens* gens, const Fr* z, const Fr* a, u
   alpha2 = fr_mul(alpha, alpha);
   ZK_LAUNCHB(ctx, "act_concat", 32ull * 6 * n, 256, k_act_concat, dim3(stream_grid(2ull * n)), 0, z, a, n, (const Fr*)lo.get(), (const Fr*)hi.get(), c, k, alpha, alpha2, T.get(),
              E.get());
-  ZK_TRY(sumcheck_ip_dev(ctx, T.get(), E.get(), 2 * n, fold_d, k + 1, fr_slot));
+  if (fs_seed32) ZK_TRY(sumcheck_ip_fs_dev(ctx, T.get(), E.get(), 2 * n, fold_d, k + 1, fr_slot));
+  else ZK_TRY(sumcheck_ip_dev(ctx, T.get(), E.get(), 2 * n, fold_d, k + 1, fr_slot));
   // the opening of T at r' = the round challenges
   return open_known_dev(ctx, gens, T.get(), 2 * n, fold_d, k + 1, g1_slot, g1_slot + 1, fr_slot + 3 * (size_t)(k + 1) + 2, &tr->queue);
 }
@@ -175,6 +186,15 @@ int zk_act_open(zk_ctx* ctx, zk_gens* gens, const zk_fr* z_d, const zk_fr* a_d, 
   return guard.finish(act_open_body(ctx, gens, reinterpret_cast<const Fr*>(z_d), reinterpret_cast<const Fr*>(a_d), n, pts_h, alpha_h, fold_h, tr));
 }
 
+int zk_act_open_fs(zk_ctx* ctx, zk_gens* gens, const zk_fr* z_d, const zk_fr* a_d, uint32_t n, const zk_fr* pts_h, const uint8_t* seed32, uint32_t layer, zk_transcript* tr) {
+  if (!ctx) return ZK_ERR_ARG;
+  (void)hipSetDevice(ctx->device);
+  if (!gens || !z_d || !a_d || !pts_h || !seed32 || !tr) return ctx->fail(ZK_ERR_ARG, "zk_act_open_fs: null argument");
+  if ((((uintptr_t)z_d) | ((uintptr_t)a_d)) & 15u) return ctx->fail(ZK_ERR_ARG, "misaligned device pointer");
+  ActGuard guard(ctx, tr);
+  return guard.finish(act_open_body(ctx, gens, reinterpret_cast<const Fr*>(z_d), reinterpret_cast<const Fr*>(a_d), n, pts_h, nullptr, nullptr, tr, seed32, layer));
+}
+
 // The verifier's side of zk_act_open.  com_d: the 2m points [com(Z) ; com(A)] (device); y_h: the three claimed evaluations Z~(p1), Z~(p2),
 // A~(p3) as the layer proofs state them; fr_h: [sumcheck 3 (k + 1) + 2][t(0)]; g1_h / inf_h: [com(u_hi)][3 k_lo + 1] affine-canonical.
 int zk_verify_act_open(zk_ctx* ctx, zk_gens* gens, const zk_g1j* com_d, uint32_t m2, uint32_t k, const zk_fr* pts_h, const zk_fr* alpha_h, const zk_fr* fold_h,
@@ -187,6 +207,14 @@ int zk_verify_act_open(zk_ctx* ctx, zk_gens* gens, const zk_g1j* com_d, uint32_t
     ctx->last_error = "verification failed: " + what;
     return ZK_OK;
   };
+  {  // canonical encodings only (see verify.hip: first_unreduced)
+    Fr rm;
+    for (int i = 0; i < 8; i++) rm.v[i] = FrP::P(i);
+    for (size_t i = 0; i < n_fr; i++)
+      if (l_gte(ldf(fr_h + i), rm)) return fail("transcript value " + std::to_string(i) + " is not a canonical field element (>= r)");
+    for (size_t i = 0; i < 3; i++)
+      if (l_gte(ldf(y_h + i), rm)) return fail("claimed evaluation " + std::to_string(i) + " is not a canonical field element (>= r)");
+  }
   const Fr alpha = ldf(alpha_h), alpha2 = fr_mul(alpha, alpha);
   // sum_x T[x] E[x] = y1 + alpha y2 + alpha^2 y3   (proof.cu:55-96)
   Fr claim = fr_add(ldf(y_h), fr_add(fr_mul(alpha, ldf(y_h + 1)), fr_mul(alpha2, ldf(y_h + 2))));

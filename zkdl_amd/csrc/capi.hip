@@ -672,6 +672,7 @@ int zk_gens_destroy(zk_gens* g) {
   if (!g) return ZK_ERR_ARG;
   if (g->ctx) {
     (void)g->ctx->settle();
+    (void)g->ctx->flush_g1_pending();  // sealed proofs still waiting for G1-batch partners hold pointers into these tables: run them now
     g->ctx->join_all();  // a sealed proof may still be reading the window tables on the G1 stream
   }
   gens_destroy(g);
@@ -757,6 +758,7 @@ int zk_fc_destroy(zk_fc* fc) {
   if (!fc) return ZK_ERR_ARG;
   if (fc->ctx) {
     (void)fc->ctx->settle();
+    (void)fc->ctx->flush_g1_pending();  // deferred G1 phases read the commitment points' tables
     fc->ctx->join_all();
   }
   if (fc->ctx) dev_free(fc->ctx, fc->weights);

@@ -325,6 +325,15 @@ FsState fs_state0(const uint8_t seed32[32], uint32_t layer, uint32_t kind, uint3
   return st;
 }
 
+void fs_state0_slot(const uint8_t seed32[32], uint32_t layer, uint32_t kind, uint32_t which, zk_fr* slot) {
+  const FsState st = fs_state0(seed32, layer, kind, which);
+  for (int i = 0; i < 8; i++) slot->v[i] = st.h[i];
+}
+int sumcheck_ip_fs_dev(zk_ctx* ctx, const Fr* a, const Fr* b, uint32_t n, Fr* fold_state_d, uint32_t k, Fr* proof_d) {
+  if (n == 0 || k > 31 || n <= ((1u << k) / 2) || n > (1u << k)) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");  // proof.cu:98-108
+  return run_sumcheck_fs<FSC_IP>(ctx, a, b, n, reinterpret_cast<FsState*>(fold_state_d + k), fold_state_d, nullptr, k, proof_d);
+}
+
 struct FsGuard {  // the same roll-back as layers.hip's ProveGuard
   zk_ctx* ctx;
   zk_transcript* tr;
@@ -536,9 +545,13 @@ int zk_leaky_prove_fs(zk_ctx* ctx, const zk_relu* relu, const zk_fr* x_d, const 
 int zk_fs_round_challenges(const uint8_t* seed32, uint32_t layer, uint32_t kind, uint32_t which, const zk_fr* coeffs_h, uint32_t k, zk_fr* out_h) {
   if (!seed32 || (k && (!coeffs_h || !out_h))) return ZK_ERR_ARG;
   FsState st = fs_state0(seed32, layer, kind, which);
+  Fr rm;
+  for (int i = 0; i < 8; i++) rm.v[i] = FrP::P(i);
   for (uint32_t r = 0; r < k; r++) {
     Fr c[3];
     memcpy(c, coeffs_h + 3 * r, sizeof c);
+    // the limbs are hashed as stored: only the canonical encoding of a coefficient may enter the chain (c and c + r would be two transcripts for one element)
+    if (l_gte(c[0], rm) || l_gte(c[1], rm) || l_gte(c[2], rm)) return ZK_ERR_RANGE;
     const Fr x = fs_round_step(st, c[0], c[1], c[2]);
     memcpy(out_h + r, &x, sizeof x);
   }

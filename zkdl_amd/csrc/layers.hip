@@ -309,7 +309,8 @@ int zk_transcript::seal(uint64_t* out8_d) {
     for (hipEvent_t e : early) ctx->event_pool.push_back(e);
     return rc;
   }
-  return submit_g1(out8_d, &early, !early.empty());
+  // the G1 phase may start behind the early chains only if EVERY queued MSM / derive job took its scalars from one of them
+  return submit_g1(out8_d, &early, !early.empty() && !queue.late_inputs);
 }
 
 // after the Fr phase has been submitted: run the G1 phase now, or -- "g1_batch" > 1 -- leave it with the context until that many
@@ -353,10 +354,10 @@ int zk_transcript::seal_pair(zk_transcript* other, uint64_t* out8_d, uint64_t* o
   // both G1 phases are always submitted: a failure of the first must not leave `other` with its Fr phase executed, its MSM queue
   // intact and no seal (the first error is what the caller sees; a failed transcript must be reset before reuse).
   // Merged execution: the events behind the zipped opening chains cover both proofs; this transcript carries them.
-  const bool ok1 = !early.empty();
+  const bool ok1 = !early.empty() && !queue.late_inputs && !other->queue.late_inputs;
   const bool same_batch = ctx->g1_batch > 1 && ctx->g1_pending.size() + 2 <= ctx->g1_batch;  // both land in one G1 batch: its waits cover both
   const int rc = submit_g1(out8_d, &early, ok1);
-  const int rc2 = other->submit_g1(other_out8_d, &early2, merged ? (ok1 && same_batch) : !early2.empty());
+  const int rc2 = other->submit_g1(other_out8_d, &early2, merged ? (ok1 && same_batch) : (!early2.empty() && !other->queue.late_inputs));
   return rc != ZK_OK ? rc : rc2;
 }
 
@@ -474,6 +475,7 @@ static int g1_phase_run(zk_ctx* ctx, const std::vector<zk_transcript*>& trs) {
     t->queue.jobs.clear();
     t->queue.derives.clear();
     t->queue.c = 0;
+    t->queue.late_inputs = false;
     for (auto& b : t->queue.keep) t->deferred_keep.push_back(std::move(b));
     t->queue.keep.clear();
     for (hipEvent_t e : t->pending_early) ctx->event_pool.push_back(e);

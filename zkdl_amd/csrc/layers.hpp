@@ -39,6 +39,9 @@ struct MsmQueue {  // MSMs enqueued by the provers, executed together by msm_flu
   std::vector<DeriveJobHost> derives;
   std::vector<DBuf<Fr>> keep;  // prepared scalars, alive until the flush
   uint32_t c = 0;
+  // a job's scalars were prepared by a recorded chain that is NOT marked early (zk_fc_prove_fs: the opening sits behind the whole hashed
+  // sumcheck): a sealed proof's G1 phase must then wait for the whole Fr phase, not only for the early chains' events
+  bool late_inputs = false;
 };
 }  // namespace zk
 
@@ -119,6 +122,10 @@ int binb_sumcheck_pme_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t 
 // (state_d: FsState*); t receives the table of the next round, one entry per word
 int fsb_sumcheck_head_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t nb, const Fr* u_d, uint32_t k, void* state_d, Fr* fold_d, Fr* proof_d, const Fr* u_rec_d, Fr* pme_d,
                           DBuf<Fr>& t, uint32_t* rounds_done);
+// sound mode, inner-product form for callers outside fs_rounds.hip (act_open.hip): fold_state_d[0..k) RECEIVES the round challenges, slot [k]
+// holds the running hash state (fs_state0_slot writes its initial value on the host, before the upload)
+int sumcheck_ip_fs_dev(zk_ctx* ctx, const Fr* a, const Fr* b, uint32_t n, Fr* fold_state_d, uint32_t k, Fr* proof_d);
+void fs_state0_slot(const uint8_t seed32[32], uint32_t layer, uint32_t kind, uint32_t which, zk_fr* slot);
 int float_to_fr_dev(zk_ctx* ctx, const float* fs, Fr* out, uint32_t rows, uint32_t rows_p, uint32_t cols, uint32_t cols_p);
 int gens_create(zk_ctx* ctx, const G1J* gens_d, uint32_t n, bool copy, zk_gens** out);
 void gens_destroy(zk_gens* g);

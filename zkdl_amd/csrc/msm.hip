@@ -819,6 +819,7 @@ int gens_prepare_full(zk_ctx* ctx, zk_gens* g, uint32_t c) {
   if (c < 4 || c > 14) return ctx->fail(ZK_ERR_ARG, "zk_gens_prepare_full: window width 4 .. 14");
   if (g->full.pts && g->full.c == c) return ZK_OK;
   if (g->full.pts) {
+    ZK_TRY(ctx->flush_g1_pending());  // deferred G1 phases (g1_batch > 1) hold pointers to the table about to be rebuilt
     ctx->wait_g1(ctx->stream);
     dev_free(ctx, g->full.pts);
     g->full = G1FullTable();
@@ -973,6 +974,7 @@ int msm_enqueue(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_
                 const uint16_t* pattern) {
   const uint32_t n = g->n;
   if (q == 0) return ZK_OK;
+  if (ctx->rec && !ctx->rec->chains.empty() && !ctx->rec->chains.back().early) queue->late_inputs = true;
   uint64_t total = (uint64_t)q * n;
   DBuf<Fr> mags;
   if (!mags.alloc(ctx, total)) return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: MSM scalars");
@@ -1018,6 +1020,7 @@ int msm_flush(zk_ctx* ctx, MsmQueue* queue) {  // on the current stream; release
   queue->derives.clear();
   queue->keep.clear();  // stream-ordered frees: safe behind the kernels just enqueued
   queue->c = 0;
+  queue->late_inputs = false;
   return rc;
 }
 
@@ -1422,6 +1425,7 @@ int me_open_flat_dev(zk_ctx* ctx, zk_gens* g, const Fr* t, const Fr* u_d, uint32
     if (!coef.alloc(ctx, (size_t)k * k)) return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: derive coefficients");
     ZK_LAUNCHB(ctx, "me_open_scalars", 32ull * k * k, 64, k_mo_derive_coef, dim3((k * k + 63) / 64), 0, u_d, k, from_com ? 0u : 1u, coef.get());
     queue->derives.push_back(DeriveJobHost{proof_d, coef.get(), k, from_com ? com_eval_d : nullptr});
+    if (ctx->rec && !ctx->rec->chains.empty() && !ctx->rec->chains.back().early) queue->late_inputs = true;
     queue->keep.push_back(std::move(coef));
     return ZK_OK;
   }

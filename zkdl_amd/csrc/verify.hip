@@ -103,6 +103,16 @@ inline G1A lda(const zk_g1a* p) {  // caller buffers need not be 16-byte aligned
   memcpy(&r, p, sizeof r);
   return r;
 }
+// Proof values are field elements in their ONE canonical encoding (Montgomery limbs below r).  c and c + r are the same element but different
+// bytes: hashed as stored (sound mode, sha256.hpp: fs_round_step) they would give different challenges, and fr_add / l_eq have no defined
+// behaviour on unreduced inputs.  Index of the first value >= r, or -1.
+inline long first_unreduced(const zk_fr* p, size_t n) {
+  Fr rm;
+  for (int i = 0; i < 8; i++) rm.v[i] = FrP::P(i);
+  for (size_t i = 0; i < n; i++)
+    if (l_gte(ld(p + i), rm)) return (long)i;
+  return -1;
+}
 inline Fr poly2(const Fr& c0, const Fr& c1, const Fr& c2, const Fr& x) { return fr_add(c0, fr_mul(x, fr_add(c1, fr_mul(x, c2)))); }
 inline bool feq(const Fr& a, const Fr& b) { return l_eq(a, b); }
 
@@ -287,6 +297,7 @@ int zk_verify_fc(zk_ctx* ctx, zk_gens* gens, const zk_g1j* com_d, uint32_t m, ui
   if ((k_bs && !u_bs_h) || (k_in && !u_in_h) || (k_out && !u_out_h)) return ctx->fail(ZK_ERR_ARG, "zk_verify_fc: null challenge vector");
   Fail fail{ctx, ok};
   (void)k_bs;
+  if (long bad = first_unreduced(fr_h, n_fr); bad >= 0) return fail("transcript value " + std::to_string(bad) + " is not a canonical field element (>= r)");
   // ---- inner-product sumcheck (proof.cu:55-96): Z~(u_out || u_bs) = <X~(., u_bs), W~(u_out, .)>
   const Fr zclaim = ld(fr_h + 3 * k_in + 2);
   if (claim_z_h) memcpy(claim_z_h, &zclaim, sizeof zclaim);
@@ -329,6 +340,7 @@ int zk_verify_open(zk_ctx* ctx, zk_gens* gens, const zk_g1j* com_d, uint32_t m, 
   const uint32_t k_lo = ceil_log2(gens->n), k_hi = ceil_log2(m);
   if (m == 0 || k != k_lo + k_hi || gens->n != (1u << k_lo) || n_g1 != 3 * (size_t)k_lo + 2) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   Fail fail{ctx, ok};
+  if (first_unreduced(value_h, 1) >= 0) return fail("the opened value is not a canonical field element (>= r)");
   bool passed = false;
   ZK_TRY(verify_opening(ctx, fail, gens, com_d, m, u_h, k, ld(value_h), g1_h, inf_h, &passed));
   if (passed) *ok = 1;
@@ -344,6 +356,7 @@ int zk_verify_relu(zk_ctx* ctx, uint32_t n, const zk_fr* u_z_h, const zk_fr* v_z
   if (n_fr != 3 * (size_t)(k + 5) + 1 + 32 + 3 * (size_t)(k + 4) + 1 + 16 + 3 * (size_t)k + 2) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   if (!u_z_h || !v_z_h || !u_r_h || !v_r_h || (k && (!u_hp_h || !v_hp_h))) return ctx->fail(ZK_ERR_ARG, "zk_verify_relu: null challenge vector");
   Fail fail{ctx, ok};
+  if (long bad = first_unreduced(fr_h, n_fr); bad >= 0) return fail("transcript value " + std::to_string(bad) + " is not a canonical field element (>= r)");
   const Fr one = fr_one();
   size_t off = 0;
   Fr finals[2];
@@ -398,6 +411,10 @@ int zk_verify_leaky(zk_ctx* ctx, uint32_t n, const zk_fr* u_z_h, const zk_fr* v_
   const size_t relu_len = 3 * (size_t)(k + 5) + 1 + 32 + 3 * (size_t)(k + 4) + 1 + 16 + 3 * (size_t)k + 2;
   if (n_fr != relu_len + 3 * (size_t)k + 2) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
   if (k && (!u_lk_h || !v_lk_h)) return ctx->fail(ZK_ERR_ARG, "zk_verify_leaky: null challenge vector");
+  if (long bad = first_unreduced(fr_h, n_fr); bad >= 0) {
+    ctx->last_error = "verification failed: transcript value " + std::to_string(bad) + " is not a canonical field element (>= r)";
+    return ZK_OK;
+  }
   int ok1 = 0;
   ZK_TRY(zk_verify_relu(ctx, n, u_z_h, v_z_h, u_r_h, v_r_h, u_hp_h, v_hp_h, fr_h, relu_len, claims_h, &ok1));
   if (!ok1) return ZK_OK;

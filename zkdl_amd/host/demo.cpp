@@ -219,9 +219,19 @@ int main(int argc, char* argv[]) {
   vector<Fr_t> challenges;
   bool use_fs = false, sound = false, do_verify = false;
   uint8_t fs_seed[32] = {};
-  int repeat = 0;
+  int repeat = 0, pipeline = 0, pipe_warmup = 5, inflight = 8, g1_batch = 3;
+  bool pipe_derive = true;
+  double spinup_ms = 400.0;
+  uint64_t chal_seed = 0x5EEDC4A100000000ull;   // bench.py: Workload.challenges draws step k's vectors from seed (this + k)
   for (int i = 3; i < argc; i++) {
     if (string(argv[i]) == "--repeat" && i + 1 < argc) repeat = atoi(argv[i + 1]);
+    if (string(argv[i]) == "--pipeline" && i + 1 < argc) pipeline = atoi(argv[i + 1]);
+    if (string(argv[i]) == "--warmup" && i + 1 < argc) pipe_warmup = atoi(argv[i + 1]);
+    if (string(argv[i]) == "--inflight" && i + 1 < argc) inflight = atoi(argv[i + 1]);
+    if (string(argv[i]) == "--g1-batch" && i + 1 < argc) g1_batch = atoi(argv[i + 1]);
+    if (string(argv[i]) == "--no-derive") pipe_derive = false;
+    if (string(argv[i]) == "--spinup-ms" && i + 1 < argc) spinup_ms = atof(argv[i + 1]);
+    if (string(argv[i]) == "--chal-seed" && i + 1 < argc) chal_seed = strtoull(argv[i + 1], nullptr, 0);
     if (string(argv[i]) == "--seed" && i + 1 < argc) zkdl::seed(strtoull(argv[i + 1], nullptr, 0) + (uint64_t)rank);   // every rank its own generators
     if (string(argv[i]) == "--dump" && i + 1 < argc) dump_dir = argv[i + 1];
     if (string(argv[i]) == "--fs") use_fs = true;
@@ -274,15 +284,13 @@ int main(int argc, char* argv[]) {
     zkdl::fs_begin(d);
     memcpy(fs_seed, d, 32);
   }
-  auto prove_all = [&]() {   // demo.cu:124-138
+  auto prove_calls = [&]() {   // demo.cu:124-138: the prove calls themselves (they append to zkdl::transcript())
     if (sound) {
       fcs[num_layer - 1].prove_fs(A_vec[num_layer - 2], Y_hat, *generators[num_layer - 1], fs_seed, num_layer - 1);
       for (int i = num_layer - 2; i >= 0; --i) {
         relus[i].prove_fs(Z_vec[i], A_vec[i], fs_seed, i);
         fcs[i].prove_fs((i > 0) ? A_vec[i - 1] : X, Z_vec[i], *generators[i], fs_seed, i);
       }
-      zk_transcript_flush(zkdl::transcript());
-      zk_ctx_sync(zkdl::ctx());
       return;
     }
     if (use_fs) zkdl::fs_call(num_layer - 1, 0);
@@ -294,6 +302,9 @@ int main(int argc, char* argv[]) {
       if (use_fs) zkdl::fs_call(i, 0);
       fcs[i].prove(A_, Z_vec[i], *generators[i]);
     }
+  };
+  auto prove_all = [&]() {
+    prove_calls();
     zk_transcript_flush(zkdl::transcript());   // the deferred MSM batch belongs to the timed region
     zk_ctx_sync(zkdl::ctx());
   };
@@ -384,7 +395,8 @@ int main(int argc, char* argv[]) {
     }
     challenges = first_challenges;
   }
-  if (dist) {   // the multi-GPU aggregate: ONE RCCL all-reduce of the ranks' transcript digests (8 x uint64 lanes), no torch
+  zk_dist* dist_h = nullptr;
+  auto dist_connect = [&]() {   // rank 0 makes the RCCL id; the 128 bytes travel through a file
     uint8_t id[128];
     const char* idfile = getenv("ZKDL_DIST_ID_FILE");
     if (rank == 0) {
@@ -405,8 +417,61 @@ int main(int argc, char* argv[]) {
         std::this_thread::sleep_for(std::chrono::milliseconds(20));
       }
     }
-    zk_dist* d = nullptr;
-    zkdl::check(zk_dist_init(zkdl::ctx(), rank, world, id, &d));
+    zkdl::check(zk_dist_init(zkdl::ctx(), rank, world, id, &dist_h));
+  };
+  if (pipeline > 0) {
+    // ---- the throughput loop (bench.py's timed region, in C++): K proofs of this statement with fresh challenges each, `inflight` transcripts
+    // rotating, `g1_batch` sealed proofs per G1 batch, derived round commitments, the run's last G1 batch in the short form; the digests are
+    // summed on the device and -- with --gpus N / --dist -- all-reduced ONCE over RCCL.  Step k draws its challenges from seed (chal_seed + k) in
+    // the reference's order (zkfc.cu:135-137, zkrelu.cu:85-98), exactly as bench.py does: same statement + same seeds = same run aggregate.
+    if (dist) dist_connect();
+    zkdl::challenge_log() = nullptr;
+    const size_t cap = (size_t)std::max({pipeline, pipe_warmup, 64});
+    zkdl::ProofPipeline pipe(cap, (uint)inflight, (uint)g1_batch, pipe_derive && !sound);
+    auto step = [&](int64_t k) {
+      if (!use_fs) zkdl::seed(chal_seed + (uint64_t)(k & 0xffffffff));
+      pipe.submit(prove_calls);
+    };
+    auto t_spin = std::chrono::steady_clock::now();
+    int64_t n_spin = 0;
+    while (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_spin).count() < spinup_ms) {   // clocks and pools up (untimed)
+      if (pipe.submitted() == pipe.capacity()) pipe.rewind(cap);
+      step(-100000 - n_spin++);
+      if (n_spin % 8 == 0) zk_ctx_sync(zkdl::ctx());
+    }
+    pipe.rewind((size_t)std::max(pipe_warmup, 1));
+    for (int k = 0; k < pipe_warmup; k++) step(-1 - k);   // its last G1 batch runs in the drain form: pools hold blocks of both shapes
+    pipe.rewind((size_t)pipeline);
+    if (dist_h) {   // warm the communicator too
+      uint64_t* w = zkdl::dalloc<uint64_t>(8);
+      zkdl::check(zk_dist_sum_rows(zkdl::ctx(), pipe.rows(), 1, w));
+      zkdl::check(zk_dist_allreduce_u64(dist_h, w, 8));
+      zk_free(zkdl::ctx(), w);
+    }
+    zk_ctx_sync(zkdl::ctx());
+    auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < pipeline; k++) step(k);
+    const double enq_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    Fr_t agg = pipe.finish(dist_h);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (rank == 0) {
+      cout << "Pipelined proof time: " << ms / 1e3 / pipeline / batch_size << " seconds per data point (" << pipeline << " proofs, " << ms / pipeline << " ms per batch-"
+           << batch_size << " proof; " << inflight << " in flight, " << g1_batch << " per G1 batch, host enqueue " << enq_ms / pipeline << " ms per proof)" << endl;
+      cout << "Run aggregate" << (dist_h ? " over " + to_string(zk_dist_world_size(dist_h)) + " ranks (RCCL all-reduce)" : string()) << ": " << agg << endl;
+    }
+    zkdl::challenge_log() = &challenges;
+    challenges = first_challenges;
+    if (dist_h) {
+      zk_dist_destroy(dist_h);
+      cout.flush();
+      zk_ctx_sync(zkdl::ctx());
+      _exit(0);
+    }
+    dist = false;
+  }
+  if (dist) {   // the multi-GPU aggregate: ONE RCCL all-reduce of the ranks' transcript digests (8 x uint64 lanes), no torch
+    dist_connect();
+    zk_dist* d = dist_h;
     uint64_t* lanes_d = zkdl::dalloc<uint64_t>(8);
     zkdl::check(zk_transcript_digest_dev(zkdl::transcript(), lanes_d));
     zkdl::check(zk_dist_allreduce_u64(d, lanes_d, 8));

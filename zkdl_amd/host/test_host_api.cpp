@@ -89,6 +89,67 @@ int main() {
   zk_transcript_counts(zkdl::transcript(), &nf, &ng);
   EXPECT(nf > 0 && ng == 1 + 3 * 3 + 1);
   EXPECT(throws([&] { zkFC bad(8, 4, w, g8); }, "Incompatible dimensions"));
+  {  // the friend free functions with the reference's iterator signatures (fr-tensor.cuh:120-126, g1-tensor.cuh:170)
+    EXPECT(eq(Fr_me(a, u.begin(), u.end()), a(u)));
+    EXPECT(eq(Fr_me(a, u.begin(), u.begin()), a(0)));                       // no challenges: t(0), fr-tensor.cu:414
+    EXPECT(eq(Fr_me(a, u.begin() + 3, u.end()), a.partial_me(std::vector<Fr_t>(u.begin(), u.begin() + 3), 1)(std::vector<Fr_t>(u.begin() + 3, u.end()))));
+    FrTensor pm = Fr_partial_me(a, u.begin(), u.begin() + 4, 8), pm2 = a.partial_me(std::vector<Fr_t>(u.begin(), u.begin() + 4), 8);
+    EXPECT(pm.size == pm2.size && eq(pm(0), pm2(0)) && eq(pm(pm.size - 1), pm2(pm2.size - 1)));
+    FrTensor idt = Fr_partial_me(a, u.begin(), u.begin(), 8);                // App. D-3: the identity
+    EXPECT(idt.size == a.size && eq(idt(17), a(17)));
+    std::vector<Fr_t> p1{one_raw}, p2 = inner_product_sumcheck(a, b, u);     // appends behind what is there
+    Fr_ip_sc(a, b, u.begin(), u.end(), p1);
+    EXPECT(p1.size() == 1 + p2.size() && memcmp(&p1[1], p2.data(), p2.size() * sizeof(Fr_t)) == 0);
+    std::vector<Fr_t> p0;
+    Fr_ip_sc(a, b, u.begin(), u.begin(), p0);
+    EXPECT(p0.size() == 2 && eq(p0[0], a(0)) && eq(p0[1], b(0)));
+    auto v = random_vec(10);
+    std::vector<Fr_t> h1, h2 = hadamard_product_sumcheck(a, b, u, v);
+    Fr_hp_sc(a, b, u.begin(), u.end(), v.begin(), v.end(), h1);
+    EXPECT(h1.size() == h2.size() && memcmp(h1.data(), h2.data(), h2.size() * sizeof(Fr_t)) == 0);
+    EXPECT(throws([&] { Fr_hp_sc(a, b, u.begin(), u.end(), v.begin(), v.end() - 1, h1); }, "Incompatible dimensions 6"));
+    EXPECT(throws([&] { Fr_hp_sc(a, FrTensor(3), u.begin(), u.end(), v.begin(), v.end(), h1); }, "Incompatible dimensions 5"));
+    std::vector<Fr_t> b1, b2 = binary_sumcheck(a, u, v);
+    Fr_bin_sc(a, u.begin(), u.end(), v.begin(), v.end(), b1);
+    EXPECT(b1.size() == b2.size() && memcmp(b1.data(), b2.data(), b2.size() * sizeof(Fr_t)) == 0);
+    std::vector<Fr_t> b0;
+    Fr_bin_sc(a, u.begin(), u.begin(), v.begin(), v.begin(), b0);
+    EXPECT(b0.size() == 1 && eq(b0[0], a(0)));
+    std::vector<Fr_t> ug = random_vec(4);
+    G1Jacobian_t m1 = G1_me(gens, ug.begin(), ug.end()), m2 = gens(ug), m0 = G1_me(gens, ug.begin(), ug.begin()), g0 = gens(0u);
+    EXPECT(memcmp(&m1, &m2, sizeof m1) == 0 && memcmp(&m0, &g0, sizeof m0) == 0);
+  }
+  {  // zkdl::ProofPipeline: sealed, rotating, batched proofs give the same transcripts as synchronous ones -- the run aggregate is the sum of the digests
+    const int K = 7;
+    auto body = [&] { relu.prove(Z, A); fc2.prove(X, Z, g8); };
+    FrTensor acc(1);
+    zk_memset_zero(zkdl::ctx(), acc.data(), sizeof(Fr_t));
+    for (int k = 0; k < K; k++) {
+      zk_transcript_reset(zkdl::transcript());
+      zkdl::seed(1000 + k);
+      body();
+      Fr_t dg;
+      zk_transcript_digest(zkdl::transcript(), &dg);
+      acc += dg;
+    }
+    for (uint g1b : {1u, 3u}) {
+      zkdl::ProofPipeline pipe(K, 4, g1b);
+      for (int k = 0; k < K; k++) { zkdl::seed(1000 + k); pipe.submit(body); }
+      EXPECT(zkdl::transcript() == zkdl::default_transcript());          // the pipeline's transcript is current only inside submit()
+      Fr_t agg = pipe.finish();
+      EXPECT(eq(agg, acc(0)));
+      EXPECT(throws([&] { pipe.submit(body); }, "zkdl::ProofPipeline: capacity exhausted"));
+      pipe.rewind(2);
+      for (int k = 0; k < 2; k++) { zkdl::seed(1000 + k); pipe.submit(body); }
+      size_t f2 = 0, g2 = 0;
+      zk_transcript_counts(pipe.transcript_of(1), &f2, &g2);
+      EXPECT(f2 == nf && g2 == ng);
+    }
+    zk_transcript_reset(zkdl::transcript());
+    zkdl::seed(5);
+    body();
+    zk_transcript_counts(zkdl::transcript(), &nf, &ng);
+  }
   std::cout << (fails ? "host api FAILED" : "host api ok") << " (" << nf << " Fr, " << ng << " G1 transcript values)" << std::endl;
   return fails ? 1 : 0;
 }

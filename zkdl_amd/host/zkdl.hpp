@@ -51,11 +51,14 @@ inline void check(int rc, const char* what = "Incompatible dimensions") {
   if (rc == ZK_ERR_SHAPE) throw std::runtime_error(what);
   throw std::runtime_error(std::string("zkdl: ") + zk_last_error(ctx()));
 }
-inline zk_transcript* transcript() {
+// the transcript prove calls append to: the process-wide default one, unless a ProofPipeline (below) has made one of its own current
+inline zk_transcript*& current_transcript() { static zk_transcript* t = nullptr; return t; }
+inline zk_transcript* default_transcript() {
   static zk_transcript* t = nullptr;
   if (!t) check(zk_transcript_create(ctx(), &t));
   return t;
 }
+inline zk_transcript* transcript() { return current_transcript() ? current_transcript() : default_transcript(); }
 template <class T> inline T* dalloc(size_t n) {
   void* p = nullptr;
   check(zk_malloc(ctx(), (n ? n : 1) * sizeof(T), &p));
@@ -199,6 +202,17 @@ inline std::ostream& operator<<(std::ostream& os, const FrTensor& A) {   // fr-t
   return os << ']';
 }
 
+// the friend free functions with the reference's iterator signatures (fr-tensor.cuh:120-126; bodies fr-tensor.cu:411-443).  The reference
+// recurses launch by launch; here each is one call into the C ABI (same field elements).
+inline Fr_t Fr_me(const FrTensor& t, std::vector<Fr_t>::const_iterator begin, std::vector<Fr_t>::const_iterator end) {
+  if (begin >= end) return t(0);                                    // fr-tensor.cu:414
+  return t(std::vector<Fr_t>(begin, end));
+}
+inline FrTensor Fr_partial_me(const FrTensor& t, std::vector<Fr_t>::const_iterator begin, std::vector<Fr_t>::const_iterator end, uint window_size) {
+  if (begin >= end) return t;                                       // fr-tensor.cu:436 (App. D-3: no challenges = the identity)
+  return t.partial_me(std::vector<Fr_t>(begin, end), window_size);
+}
+
 // ------------------------------------------------------------------ proof.cuh:13-34
 namespace zkdl {
 // additive: when set, every challenge random_vec hands out is also appended here, in draw order (demo --dump:
@@ -255,6 +269,31 @@ inline std::vector<Fr_t> binary_sumcheck(const FrTensor& a, std::vector<Fr_t> u,
   std::vector<Fr_t> proof(3 * u.size() + 1);
   zkdl::check(zk_sumcheck_binary(zkdl::ctx(), a.gpu_data, a.size, u.data(), v.data(), (uint32_t)u.size(), proof.data()));
   return proof;
+}
+
+// proof.cu:72-96, 110-137, 165-188: the recursive provers behind the three wrappers above, appending to `proof`.  Unlike the wrappers they make no
+// size checks against the number of challenges (the recursion simply runs end - begin rounds); the C ABI needs a.size <= 2^rounds (a shorter
+// tensor is zero-padded, which is what the reference's bounds-checked kernels compute), so a longer one is rejected here.
+inline void Fr_ip_sc(const FrTensor& a, const FrTensor& b, std::vector<Fr_t>::const_iterator begin, std::vector<Fr_t>::const_iterator end, std::vector<Fr_t>& proof) {
+  if (a.size != b.size) throw std::runtime_error("Incompatible dimensions");
+  if (begin >= end) { proof.push_back(a(0)); proof.push_back(b(0)); return; }
+  auto p = inner_product_sumcheck(a, b, std::vector<Fr_t>(begin, end));
+  proof.insert(proof.end(), p.begin(), p.end());
+}
+inline void Fr_hp_sc(const FrTensor& a, const FrTensor& b, std::vector<Fr_t>::const_iterator u_begin, std::vector<Fr_t>::const_iterator u_end,
+                     std::vector<Fr_t>::const_iterator v_begin, std::vector<Fr_t>::const_iterator v_end, std::vector<Fr_t>& proof) {
+  if (a.size != b.size) throw std::runtime_error("Incompatible dimensions 5");
+  if (v_end - v_begin != u_end - u_begin) throw std::runtime_error("Incompatible dimensions 6");
+  if (v_begin >= v_end) { proof.push_back(a(0)); proof.push_back(b(0)); return; }
+  auto p = hadamard_product_sumcheck(a, b, std::vector<Fr_t>(u_begin, u_end), std::vector<Fr_t>(v_begin, v_end));
+  proof.insert(proof.end(), p.begin(), p.end());
+}
+inline void Fr_bin_sc(const FrTensor& a, std::vector<Fr_t>::const_iterator u_begin, std::vector<Fr_t>::const_iterator u_end, std::vector<Fr_t>::const_iterator v_begin,
+                      std::vector<Fr_t>::const_iterator v_end, std::vector<Fr_t>& proof) {
+  if (v_end - v_begin != u_end - u_begin) throw std::runtime_error("Incompatible dimensions 6");
+  if (v_begin >= v_end) { proof.push_back(a(0)); return; }
+  auto p = binary_sumcheck(a, std::vector<Fr_t>(u_begin, u_end), std::vector<Fr_t>(v_begin, v_end));
+  proof.insert(proof.end(), p.begin(), p.end());
 }
 
 // ------------------------------------------------------------------ G1 tensors (g1-tensor.cuh:65-174)
@@ -400,6 +439,12 @@ class G1TensorJacobian : public G1Tensor {
   friend class Commitment;
   friend class zkFC;
 };
+
+// g1-tensor.cuh:170, g1-tensor.cu:477-484
+inline G1Jacobian_t G1_me(const G1TensorJacobian& t, std::vector<Fr_t>::const_iterator begin, std::vector<Fr_t>::const_iterator end) {
+  if (begin >= end) return t(0);
+  return t(std::vector<Fr_t>(begin, end));
+}
 
 // ------------------------------------------------------------------ Commitment (commitment.cuh:8-23)
 class Commitment : public G1TensorJacobian {
@@ -582,6 +627,94 @@ class zkReLU {
     return ok ? std::string() : std::string(zk_last_error(zkdl::ctx()));
   }
 };
+
+// ------------------------------------------------------------------ additive: the pipelined prover (what bench.py's timed loop does, in C++)
+// The reference's driver proves ONE statement and waits (demo.cu:124-140).  A prover that serves a stream of statements keeps several
+// proofs in flight: every proof is recorded into its own transcript and SEALED (zk_transcript_seal) -- its G1 phase (MSM batch, derived round
+// commitments, canonical form, digest) then runs on the library's G1 stream under the Fr phases of the following proofs; `g1_batch` sealed
+// proofs share one G1 batch; `inflight` transcripts rotate.  Every proof leaves its digest (8 x u64 lanes) in its own row of a device
+// buffer; finish() waits for all of them, sums the rows on the device (zk_dist_sum_rows), optionally all-reduces the sum over RCCL
+// (zk_dist_allreduce_u64: independent proof batches per GPU, ONE collective per run) and returns the aggregate as a field element.
+//   zkdl::ProofPipeline pipe(K);                       // throughput configuration: 8 in flight, 3 per G1 batch, derived round commitments
+//   for (k = 0; k < K; k++) pipe.submit([&] { fcs[L-1].prove(...); for (i = L-2 .. 0) { relus[i].prove(...); fcs[i].prove(...); } });
+//   Fr_t aggregate = pipe.finish();
+// The prove calls inside submit() are the reference's, unchanged: they append to zkdl::transcript(), which is the pipeline's current
+// transcript while the body runs.  Pure scheduling: every transcript holds the same values as a synchronous proof of the same statement
+// with the same challenges (tests/test_gpu_host_api.py compares the run aggregate with bench.py's).
+namespace zkdl {
+class ProofPipeline {
+  std::vector<zk_transcript*> trs_;
+  uint64_t* rows_ = nullptr;   // [capacity][8] on the device
+  size_t alloc_, cap_, n_ = 0, drain_ = 0;
+  uint g1_batch_;
+  bool derive_, drained_ = false;
+
+ public:
+  // capacity = proofs until finish(); the last `drain` of them (default: one G1 batch) take the short G1 form -- every round commitment an MSM,
+  // G1 phases unbatched -- because they have no later proof to hide the longer derived form under
+  explicit ProofPipeline(size_t capacity, uint inflight = 8, uint g1_batch = 3, bool derive_rounds = true, int drain = -1)
+      : alloc_(capacity ? capacity : 1), cap_(alloc_), g1_batch_(g1_batch ? g1_batch : 1), derive_(derive_rounds) {
+    drain_ = derive_ ? (drain < 0 ? g1_batch_ : (size_t)drain) : 0;
+    trs_.resize(inflight < 2 ? 2 : inflight);
+    for (auto& t : trs_) check(zk_transcript_create(ctx(), &t));
+    rows_ = dalloc<uint64_t>(8 * cap_);
+    std::vector<uint64_t> z(8 * cap_, 0);
+    check(zk_memcpy_h2d(ctx(), rows_, z.data(), z.size() * sizeof(uint64_t)));
+    configure(false);
+  }
+  ProofPipeline(const ProofPipeline&) = delete;
+  ~ProofPipeline() {
+    current_transcript() = nullptr;
+    for (auto t : trs_) if (t) zk_transcript_destroy(t);
+    zk_free(ctx_slot(), rows_);
+    zk_set_flag(ctx(), "derive_rounds", 0);   // back to the library's defaults (synchronous use)
+    zk_set_flag(ctx(), "g1_batch", 1);
+    zk_set_flag(ctx(), "g1_streams", 0);
+  }
+  void configure(bool drain_form) {
+    check(zk_set_flag(ctx(), "derive_rounds", derive_ && !drain_form ? 1 : 0));
+    check(zk_set_flag(ctx(), "g1_batch", drain_form ? 1 : (int)g1_batch_));
+    check(zk_set_flag(ctx(), "g1_streams", g1_batch_ > 1 ? 1 : 0));   // batched G1 phases want ONE G1 stream
+  }
+  size_t submitted() const { return n_; }
+  size_t capacity() const { return cap_; }
+  // the transcript the k-th submitted proof went to (valid until `inflight` more proofs have been submitted)
+  zk_transcript* transcript_of(size_t k) const { return trs_[k % trs_.size()]; }
+  const uint64_t* rows() const { return rows_; }
+  template <class Body> void submit(Body&& body) {
+    if (n_ >= cap_) throw std::runtime_error("zkdl::ProofPipeline: capacity exhausted");
+    if (!drained_ && drain_ && n_ + drain_ >= cap_) { configure(true); drained_ = true; }
+    zk_transcript* tr = trs_[n_ % trs_.size()];
+    check(zk_transcript_reset(tr));          // waits for this transcript's own earlier G1 phase only
+    current_transcript() = tr;
+    try { body(); } catch (...) { current_transcript() = nullptr; throw; }
+    current_transcript() = nullptr;
+    check(zk_transcript_seal(tr, rows_ + 8 * n_));
+    ++n_;
+  }
+  // waits for every sealed proof, sums the digest rows on the device, all-reduces the sum over `dist` (if given), returns the aggregate
+  Fr_t finish(zk_dist* dist = nullptr) {
+    uint64_t* agg = dalloc<uint64_t>(8);
+    uint64_t lanes[8];
+    check(zk_dist_sum_rows(ctx(), rows_, n_, agg));
+    if (dist) check(zk_dist_allreduce_u64(dist, agg, 8));
+    check(zk_memcpy_d2h(ctx(), lanes, agg, sizeof lanes));
+    zk_free(ctx(), agg);
+    Fr_t out;
+    zk_dist_lanes_to_fr(lanes, &out);
+    return out;
+  }
+  // start over with the same transcripts (the next run's rows overwrite this one's)
+  void rewind(size_t capacity = 0) {
+    check(zk_ctx_sync(ctx()));
+    if (capacity > alloc_) throw std::runtime_error("zkdl::ProofPipeline: rewind beyond the allocated rows");
+    if (capacity) cap_ = capacity;
+    n_ = 0;
+    drained_ = false;
+    configure(false);
+  }
+};
+}  // namespace zkdl
 
 // ------------------------------------------------------------------ Timer (timer.hpp:6-22)
 #include <chrono>

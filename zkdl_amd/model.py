@@ -61,12 +61,23 @@ def main():
     ap.add_argument("--bias", action="store_true", help="Linear layers with bias (the reference's model.py has none; the demo's loader folds them into the matrices)")
     ap.add_argument("--act", default="relu", help="hidden activations, one spec or a comma-separated list (one per hidden layer): relu | leaky:<s> (negative slope "
                     "2^-s) | identity | none (consecutive Linear layers); the reference's model.py has ReLU only")
+    ap.add_argument("--like-bench", type=int, default=None, metavar="RANK", help="weights and input exactly as bench.py's Workload draws them for that rank (numpy generator "
+                    "1000 + RANK: uniform(+-1/sqrt(in)) matrices, N(0,1) input): `demo --seed 0xC0FFEE --pipeline K` then proves the statements bench.py times")
     ap.add_argument("--out-dir", default=".")
     args = ap.parse_args()
     dims = [int(x) for x in args.dims.split(",")]
     os.makedirs(args.out_dir, exist_ok=True)
     model = build(dims, args.seed, args.bias, tuple(args.act.split(",")))
     x = torch.randn(args.batch, dims[0])
+    if args.like_bench is not None:                      # bench.py: Workload.__init__ (same draws in the same order)
+        import numpy as np
+        rng = np.random.default_rng(1000 + args.like_bench)
+        linears = [m for m in model if isinstance(m, nn.Linear)]
+        with torch.no_grad():
+            for m, (n_in, n_out) in zip(linears, zip(dims[:-1], dims[1:])):
+                w = rng.uniform(-1.0 / np.sqrt(n_in), 1.0 / np.sqrt(n_in), size=(n_in, n_out)).astype(np.float32)
+                m.weight.copy_(torch.from_numpy(np.ascontiguousarray(w.T)))
+        x = torch.from_numpy(rng.standard_normal((args.batch, dims[0])).astype(np.float32))
     with torch.no_grad():
         y = model(x)
     save_tensor(x, os.path.join(args.out_dir, "sample_input.pt"))

@@ -111,9 +111,12 @@ def verify_mlp_fs(zk, dims, batch, gens, coms, x_fr, y_fr, blob):
     """Verify a proof made by prove_mlp_fs: the challenges are re-derived from the statement AND the proof's round messages, then every
     check of verify_mlp runs.  A changed round message changes every later challenge of its sumcheck, so the prover cannot have chosen the
     message knowing them.  Returns (ok, message, open_claims)."""
+    from .capi import ZkError
     try:
         fr, _, _ = parse_transcript(blob)
         chal = fs_round_mode_challenges(statement_digest(zk, dims, batch, gens, coms, x_fr, y_fr), dims, batch, fr)
+    except ZkError:                      # zk_fs_round_challenges: a round message that is not a canonical field element (>= r)
+        return False, "a round message is not a canonical field element", []
     except ValueError as e:
         return False, str(e), []
     return verify_mlp(zk, dims, batch, gens, coms, x_fr, y_fr, blob, chal=chal)
@@ -275,15 +278,36 @@ def claimed_activation_values(dims, open_claims):
 KIND_ACT = 2
 
 
-def act_open_challenges(seed, dims, batch):
+def act_statement_seed(zk, seed, act_coms):
+    """The seed every challenge of the activation openings comes from: the statement digest AND the activation commitments [com(Z_i) ; com(A_i)]
+    (affine-canonical bytes + infinity flags).  A prover therefore has to fix com(Z_i), com(A_i) before it learns alpha or the opening point
+    (derived from the statement alone, the challenges were known before the commitments were chosen)."""
+    parts = [b"zkdl-amd/act/v1", bytes(seed)]
+    for c in act_coms:
+        aff, inf = zk.g1_to_affine(c)
+        parts += [sha256(aff.tobytes()), sha256(inf.tobytes())]
+    return sha256(b"".join(parts))
+
+
+def act_layer_seed(aseed, layer, ys, pts):
+    """Sound mode, per hidden layer: the activation seed, the layer, the three claimed evaluations as the layer proofs state them and the three
+    points they are claimed at -- everything alpha may depend on (zk_act_open_fs)."""
+    parts = [b"zkdl-amd/act-layer/v1", bytes(aseed), struct.pack("<I", layer)]
+    parts += [np.ascontiguousarray(np.asarray(y, dtype=np.uint32).reshape(8)).tobytes() for y in ys]
+    parts += [np.ascontiguousarray(np.asarray(p, dtype=np.uint32).reshape(-1, 8)).tobytes() for p in pts]
+    return sha256(b"".join(parts))
+
+
+def act_open_challenges(aseed, dims, batch):
     """Per hidden layer i: (alpha, fold) -- the combination challenge of its three claims and the k + 1 round challenges of the claim-reduction
-    sumcheck (= the opening point); statement-derived like every other challenge of the throughput mode."""
+    sumcheck (= the opening point), derived from act_statement_seed() like every other challenge of the throughput mode: a public-coin schedule
+    fixed by the statement and the commitments, NOT a function of the prover's round messages (the sound variant is prove_activation_openings_fs)."""
     sh = layer_shapes(dims)
     kb = ceil_log2(1 << ceil_log2(batch))
     out = []
     for i in range(len(sh) - 1):
         k = kb + ceil_log2(sh[i]["out_p"])
-        out.append((fs_derive(seed, i, KIND_ACT, 0, 1), fs_derive(seed, i, KIND_ACT, 1, k + 1)))
+        out.append((fs_derive(aseed, i, KIND_ACT, 0, 1), fs_derive(aseed, i, KIND_ACT, 1, k + 1)))
     return out
 
 
@@ -298,12 +322,49 @@ def act_claim_points(dims, chal):
     return out
 
 
-def prove_activation_openings(zk, dims, batch, gens, Z, A, chal, seed, tr):
+def act_claimed_values(dims, batch, fr):
+    """Per hidden layer i: (y1, y2, y3) = Z_i~(p1), Z_i~(p2), A_i~(p3) read from the layer proofs' Fr values (SURVEY App. A.6 layout): zkFC's slice
+    ends [.. a(0) = X~, b(0) = W~][Z~(u_out||u_bs)][t(0)], the ReLU's Hadamard sumcheck ends [.. (Z)~(v_hp), sign~(v_hp)]."""
+    sh = layer_shapes(dims)
+    kb = ceil_log2(1 << ceil_log2(batch))
+    L = len(sh)
+    z1, z2, a3 = {}, {}, {}
+    off = 0
+    for kind, i in call_order(L):
+        s = sh[i]
+        if kind == "fc":
+            k_in = ceil_log2(s["in_p"])
+            z1[i] = fr[off + 3 * k_in + 2]
+            if i > 0:
+                a3[i - 1] = fr[off + 3 * k_in]
+            off += 3 * k_in + 4
+        else:
+            k = kb + ceil_log2(s["out_p"])
+            nf = 3 * (k + 5) + 1 + 32 + 3 * (k + 4) + 1 + 16 + 3 * k + 2
+            z2[i] = fr[off + nf - 2]
+            off += nf
+    return [(z1[i], z2[i], a3[i]) for i in range(L - 1)]
+
+
+def prove_activation_openings(zk, dims, batch, gens, Z, A, chal, aseed, tr):
     """Behind the layer proofs already recorded on `tr`: one claim-reduction sumcheck and ONE opening of [Z_i ; A_i] per hidden layer
-    (zk_act_open); their MSMs join the transcript's deferred batch."""
+    (zk_act_open); their MSMs join the transcript's deferred batch.  aseed = act_statement_seed(zk, statement digest, act_coms)."""
     pts = act_claim_points(dims, chal)
-    for i, (alpha, fold) in enumerate(act_open_challenges(seed, dims, batch)):
+    for i, (alpha, fold) in enumerate(act_open_challenges(aseed, dims, batch)):
         zk.act_open(gens[i], Z[i], A[i], pts[i], alpha, fold, tr)
+
+
+def prove_activation_openings_fs(zk, dims, batch, gens, Z, A, seed, aseed, tr):
+    """The sound variant, behind prove_mlp_fs(.., tr): the layer proofs are finished and read back (their hashed round challenges are the claim
+    points p2, p3, and alpha has to depend on the claimed values), then every layer's reduction runs with alpha and its round challenges hashed
+    from act_layer_seed() and its own round messages on the device (zk_act_open_fs).  One host read per proof: an extension, not the headline loop."""
+    tr.flush()
+    fr, _ = tr.read()
+    chal = fs_round_mode_challenges(seed, dims, batch, fr)
+    pts = act_claim_points(dims, chal)
+    ys = act_claimed_values(dims, batch, fr)
+    for i in range(len(dims) - 2):
+        zk.act_open_fs(gens[i], Z[i], A[i], pts[i], act_layer_seed(aseed, i, ys[i], pts[i]), i, tr)
 
 
 def act_open_lengths(dims, batch):
@@ -313,15 +374,19 @@ def act_open_lengths(dims, batch):
     return [(3 * (kb + ceil_log2(s["out_p"]) + 1) + 3, 3 * ceil_log2(s["n_gens"]) + 2) for s in sh[:-1]]
 
 
-def verify_mlp_with_activation_openings(zk, dims, batch, gens, coms, act_coms, x_fr, y_fr, blob, chal=None):
+def verify_mlp_with_activation_openings(zk, dims, batch, gens, coms, act_coms, x_fr, y_fr, blob, chal=None, sound=False):
     """Verify the layer proofs AND the activation openings behind them.  act_coms[i] = DevArray of the 2m points [com(Z_i) ; com(A_i)] (public, like
     the weight commitments).  What verify_mlp returns as open claims on Z_i / A_i is now bound to those commitments; what stays open is what the
-    reference's ReLU leaves unbound (bit tensors, sign).  Returns (ok, message, remaining open claims)."""
+    reference's ReLU leaves unbound (bit tensors, sign).  Returns (ok, message, remaining open claims).
+    sound=False: every challenge derived from the statement (and, for the openings, the activation commitments) -- a public-coin schedule, as in
+    the reference, whose coins are drawn before any round runs; a consistency check, not a sound non-interactive argument.
+    sound=True (a proof made by prove_mlp_fs + prove_activation_openings_fs): the layer proofs' round challenges, alpha and the reductions' round
+    challenges are all re-derived from the proof's own messages."""
+    from .capi import ZkError
     sh = layer_shapes(dims)
     L = len(sh)
     seed = statement_digest(zk, dims, batch, gens, coms, x_fr, y_fr)
-    if chal is None:
-        chal = fs_challenges(seed, dims, batch)
+    aseed = act_statement_seed(zk, seed, act_coms)
     try:
         fr, aff, inf = parse_transcript(blob)
     except ValueError as e:
@@ -331,6 +396,15 @@ def verify_mlp_with_activation_openings(zk, dims, batch, gens, coms, act_coms, x
     if fr.shape[0] < nf_act or aff.shape[0] < ng_act:
         return False, "transcript does not have the shape of this model's proof", []
     nf0, ng0 = fr.shape[0] - nf_act, aff.shape[0] - ng_act
+    try:
+        if sound:
+            chal = fs_round_mode_challenges(seed, dims, batch, fr[:nf0])
+        elif chal is None:
+            chal = fs_challenges(seed, dims, batch)
+    except ZkError:
+        return False, "a round message is not a canonical field element", []
+    except ValueError as e:
+        return False, str(e), []
     head = b"ZKDLTR01" + struct.pack("<QQ", nf0, ng0) + fr[:nf0].tobytes() + aff[:ng0].tobytes() + inf[:ng0].tobytes()
     ok, msg, open_claims = verify_mlp(zk, dims, batch, gens, coms, x_fr, y_fr, head, chal=chal)
     if not ok:
@@ -340,10 +414,20 @@ def verify_mlp_with_activation_openings(zk, dims, batch, gens, coms, act_coms, x
     kb = ceil_log2(1 << ceil_log2(batch))
     of, og = nf0, ng0
     closed = set()
-    for i, (alpha, fold) in enumerate(act_open_challenges(seed, dims, batch)):
+    static = None if sound else act_open_challenges(aseed, dims, batch)
+    for i in range(L - 1):
         nf, ng = lens[i]
         ys = [by["Z_%d~(u_out||u_bs)" % i], by["relu_%d:Z~(v_hp)" % i], by["A_%d~(u_in||u_bs)" % i]]
         k = kb + ceil_log2(sh[i]["out_p"])
+        if sound:
+            lseed = act_layer_seed(aseed, i, ys, pts[i])
+            alpha = fs_derive(lseed, i, KIND_ACT, 0, 1)
+            try:
+                fold = fs_round_challenges(lseed, i, KIND_ACT, 0, fr[of:of + 3 * (k + 1)])
+            except ZkError:
+                return False, "activation opening, layer %d: a round message is not a canonical field element" % i, open_claims
+        else:
+            alpha, fold = static[i]
         ok, msg = zk.verify_act_open(gens[i], act_coms[i], k, pts[i], alpha, fold, ys, fr[of:of + nf], aff[og:og + ng], inf[og:og + ng])
         if not ok:
             return False, "activation opening, layer %d: %s" % (i, msg), open_claims
