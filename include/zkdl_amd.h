@@ -141,7 +141,7 @@ int zk_g1_to_affine(zk_ctx* ctx, const zk_g1j* a_d, uint32_t n, zk_g1a* out_d, u
  * different Jacobian representatives). */
 enum { ZK_MSM_LITERAL = 0, ZK_MSM_PIPPENGER = 1 };
 int zk_set_msm_mode(zk_ctx* ctx, int mode);
-int zk_set_msm_window(zk_ctx* ctx, uint32_t window_bits);   /* 0 = automatic */
+int zk_set_msm_window(zk_ctx* ctx, uint32_t window_bits);   /* 0 = automatic; else 2 .. 13 (ZK_ERR_ARG otherwise) */
 /* Scheduling / representation switches, on by default unless noted; none of them changes a transcript value:
  *   "relu_packed"   ReLU aux sumchecks and partial_me read the packed bits instead of the one-Fr-per-bit tensors
  *   "relu_bytes"    ... and take rounds 0-4 (32-bit words) / 0-3 (16-bit) from weighted byte histograms instead of the
@@ -325,6 +325,14 @@ int zk_verify_relu(zk_ctx* ctx, uint32_t n, const zk_fr* u_z_h, const zk_fr* v_z
  * own round messages exactly like the reference's pre-drawn coins. */
 int zk_fs_derive(const uint8_t* seed32, uint32_t layer, uint32_t kind, uint32_t vec, uint32_t len, zk_fr* out_h);
 int zk_sha256(const void* data, size_t len, uint8_t* out32);
+
+/* ---------------------------------------------------------------- diagnostics
+ * The device field functions every kernel is built from, applied element-wise (one element per lane), so that known-answer vectors reach each of them
+ * directly.  which: 0 = Fr (8 x u32 per element), 1 = Fp (12 x u32) -- field.hpp, the reference's blstrs__scalar__Scalar_* / blstrs__fp__Fp_*
+ * (bls12-381.cu:499-593, 652-963); 2 = Fr through the 9 x 29-bit lazily reduced form of the big sumcheck rounds (fs29.hpp; op 5..7: the UNREDUCED
+ * product summed as columns), 3 = Fp through the 14 x 28-bit form of the MSM pipeline (fq28.hpp; no mont / unmont).  op: 0 add, 1 sub, 2 mul, 3 sqr,
+ * 4 double, 5 mont, 6 unmont, 7 neg.  b_d may be NULL for unary ops.  Results are canonical.  Nothing on the proving path calls this. */
+int zk_field_selftest(zk_ctx* ctx, int which, int op, const void* a_d, const void* b_d, void* out_d, uint32_t n);
 
 /* ---------------------------------------------------------------- activation commitments inside the proof
  * The reference's "commitment of activations / proof compression" future work (README.md:131-135).  With Z_i and A_i committed row-wise over

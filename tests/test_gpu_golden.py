@@ -86,3 +86,33 @@ def test_constants_are_the_reference_constants(zk, gold):
     assert np.array_equal(zk.fr_unmont(zk.upload(m)).download(), one)
     r2 = unhex([gold["constants"]["fr_r2"]], 8)
     assert np.array_equal(zk.fr_mul(zk.upload(one), zk.upload(r2)).download(), m)
+
+
+def test_every_device_field_function_reproduces_the_reference_vectors(zk, gold):
+    """zk_field_selftest runs the device functions the kernels are built from, one element per lane: Scalar_* AND Fp_* (bls12-381.cu:499-593, 652-963) as
+    field.hpp implements them -- f_double and f_sqr directly, not through a + a / a * a -- and the same operations through the lazily reduced limb forms
+    the hot loops use (fs29.hpp: 9 x 29 bits for the big sumcheck rounds, incl. the unreduced column accumulation; fq28.hpp: 14 x 28 bits for the MSM
+    pipeline).  Expected values: the reference's own compiled arithmetic (tests/golden/prims.json)."""
+    ADD, SUB, MUL, SQR, DOUBLE, MONT, UNMONT, NEG = range(8)
+    for name, width, plain, lazy in (("fr", 8, 0, 2), ("fp", 12, 1, 3)):
+        sec = gold[name]
+        a, b, un = zk.upload(unhex(sec["a"], width)), zk.upload(unhex(sec["b"], width)), zk.upload(unhex(sec["un"], width))
+        for which in (plain, lazy):
+            for op, key in ((ADD, "add"), (SUB, "sub"), (MUL, "mul")):
+                assert np.array_equal(zk.field_selftest(which, op, a, b).download(), unhex(sec[key], width)), (name, which, key)
+            for op, key in ((SQR, "sqr"), (DOUBLE, "double")):
+                assert np.array_equal(zk.field_selftest(which, op, un).download(), unhex(sec[key], width)), (name, which, key)
+        for op, key in ((MONT, "mont"), (UNMONT, "unmont")):
+            assert np.array_equal(zk.field_selftest(plain, op, un).download(), unhex(sec[key], width)), (name, key)
+        # neg: a + (-a) = 0 through the reference-checked add
+        neg = zk.field_selftest(plain, NEG, un)
+        assert not zk.field_selftest(plain, ADD, un, neg).download().any()
+    # 29-bit form, the unreduced product accumulated as columns and reduced once (what the round coefficients are made of) == the Montgomery product
+    sec = gold["fr"]
+    a, b = zk.upload(unhex(sec["a"], 8)), zk.upload(unhex(sec["b"], 8))
+    assert np.array_equal(zk.field_selftest(2, MONT, a, b).download(), unhex(sec["mul"], 8))
+    # 28-bit form: negation
+    un = zk.upload(unhex(gold["fp"]["un"], 12))
+    assert not zk.field_selftest(1, ADD, un, zk.field_selftest(3, NEG, un)).download().any()
+    assert np.array_equal(zk.field_selftest(1, MUL, zk.upload(unhex([gold["constants"]["fp_one"]], 12)), zk.upload(unhex([gold["constants"]["fp_one"]], 12))).download(),
+                          unhex([gold["constants"]["fp_one"]], 12))

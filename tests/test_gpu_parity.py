@@ -369,6 +369,16 @@ def test_msm_window_sweep_gives_same_points(zk, oracle, rng, window):
         zk.set_msm_window(0)
 
 
+def test_msm_window_outside_the_supported_range_is_refused(zk):
+    """The counting sort holds one LDS counter per bucket: windows of 2 .. 13 bits.  Wider ones used to be clamped to 13 silently."""
+    from zkdl_amd.capi import ZkError
+    for w in (1, 14, 16, 17, 64):
+        with pytest.raises(ZkError):
+            zk.set_msm_window(w)
+    zk.set_msm_window(13)
+    zk.set_msm_window(0)
+
+
 def test_derived_round_commitments_equal_the_msm_ones(zk, oracle):
     """`derive_rounds`: T_1 .. T_{k-1} of every opening from the folding relation (scalar multiplications of T_0, T0_j, T1_j
     behind the MSM batch) instead of as MSMs -- the same group elements, hence the same affine transcript and the oracle's."""

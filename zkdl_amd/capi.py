@@ -35,7 +35,7 @@ zk_relu_destroy zk_relu_forward zk_relu_sign zk_relu_mag_bin zk_relu_rem_bin zk_
 zk_transcript_destroy zk_transcript_reset zk_transcript_flush zk_transcript_counts zk_transcript_read zk_transcript_read_affine
 zk_transcript_digest zk_transcript_digest_dev zk_transcript_serialize zk_transcript_seal zk_transcript_seal_pair zk_transcript_stream
 zk_verify_fc zk_verify_relu zk_verify_open zk_fs_derive zk_sha256 zk_fc_prove_fs zk_relu_prove_fs zk_leaky_prove_fs zk_fs_round_challenges zk_relu_set_activation zk_leaky_prove zk_verify_leaky zk_act_open zk_act_open_fs zk_verify_act_open zk_dist_unique_id zk_dist_init zk_dist_world_size zk_dist_sum_rows zk_dist_allreduce_u64
-zk_dist_lanes_to_fr zk_dist_destroy zk_gens_prepare_full""".split()
+zk_dist_lanes_to_fr zk_dist_destroy zk_gens_prepare_full zk_field_selftest""".split()
 
 
 class ZkError(RuntimeError):
@@ -258,6 +258,12 @@ class Zk:
     def _fr2(self, fn, a):
         out = self.empty(a.n, 8)
         self._chk(getattr(self.lib, fn)(self.ctx, _vp(a.ptr), _vp(out.ptr), _u32(a.n)))
+        return out
+
+    def field_selftest(self, which, op, a, b=None):
+        """zk_field_selftest: the device field functions element-wise (which 0 Fr / 1 Fp / 2 Fr via 29-bit limbs / 3 Fp via 28-bit limbs)."""
+        out = self.empty(a.n, a.width)
+        self._chk(self.lib.zk_field_selftest(self.ctx, ctypes.c_int(which), ctypes.c_int(op), _vp(a.ptr), _vp(b.ptr if b is not None else 0), _vp(out.ptr), _u32(a.n)))
         return out
 
     def fr_neg(self, a): return self._fr2("zk_fr_neg", a)

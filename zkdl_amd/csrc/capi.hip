@@ -654,7 +654,8 @@ int zk_set_flag(zk_ctx* ctx, const char* name, int value) {
 }
 int zk_set_msm_window(zk_ctx* ctx, uint32_t w) {
   CHECK_CTX(ctx);
-  if (w > 16) return ctx->fail(ZK_ERR_ARG, "MSM window must be 0 (auto) or 1..16 bits");
+  // 2 .. 13: the counting sort keeps one LDS counter per bucket (2^(c-1) + 1 of them); wider windows used to be clamped silently
+  if (w == 1 || w > 13) return ctx->fail(ZK_ERR_ARG, "MSM window must be 0 (auto) or 2..13 bits");
   ctx->msm_window = w;
   return ZK_OK;
 }

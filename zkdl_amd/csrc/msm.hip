@@ -592,7 +592,7 @@ int g1_canonicalise_multi_dev(zk_ctx* ctx, const CanonRanges& r) {
 }
 
 uint32_t msm_pick_window(zk_ctx* ctx, uint32_t bits) {
-  if (ctx->msm_window) return ctx->msm_window < 2 ? 2 : (ctx->msm_window > 13 ? 13 : ctx->msm_window);
+  if (ctx->msm_window) return ctx->msm_window;  // zk_set_msm_window admits 2 .. 13 only
   return bits <= 24 ? 7 : 10;  // short scalars (quantised weights): two 7-bit windows; full width: 26 x 10 bits
 }
 uint32_t msm_num_windows(uint32_t bits, uint32_t c) {
