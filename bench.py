@@ -453,6 +453,11 @@ def compact_line(out):
     line = _r(line)
     for k in ("value", "ms_per_step"):          # the headline keeps its full precision (value == ms_per_step / batch / n_gpus exactly)
         line[k] = out[k]
+    rl = line["roofline"]                       # ... and the fractions are those of the (rounded) numbers beside them
+    if rl.get("achieved") is not None and rl.get("peak"):
+        rl["frac"] = rl["achieved"] / rl["peak"]
+    if rl.get("hbm") and rl["hbm"].get("achieved") is not None:
+        rl["hbm"]["frac"] = rl["hbm"]["achieved"] / rl["hbm"]["peak"]
     return line
 
 

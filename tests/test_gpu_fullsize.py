@@ -317,3 +317,55 @@ def test_mlp18m_batch1_whole_proof_matches_oracle(zk, oracle):
     assert eq(fr_g, fr_o)
     aff_o, inf_o = oracle.g1_to_affine(g1_o)
     assert eq(aff_g, aff_o) and eq(inf_g, inf_o)
+
+
+def test_deep4096x64_at_full_depth_with_oracle_parity_at_width_4096(zk):
+    """BASELINE configs[4] at its stated size: width 4096, depth 64, batch 256 -- all 64 zkFC::prove and 63 zkReLU::prove calls in one
+    transcript (4096 generators per layer, 12 me_open rounds: demo.cu:81, zkfc.cu:92-93).  Every layer's Fr recurrences are verified
+    (check_workload: sumcheck round consistency and final claims of all 64 zkFC slices, boolean vanishing and recombination of three zkReLU slices,
+    scheduling invariance and the sealed / pipelined form of the whole transcript), and
+    the CPU oracle -- the restatement of the reference algorithm -- reproduces the last layer's zkFC (2^24 weights, 4096 generators) and the
+    last hidden layer's zkReLU + zkFC at batch 256 bit for bit (Fr) / in affine-canonical form (G1), from the GPU's own tensors and challenges.
+    The per-proof time of the same loop is what `bench.py --workload deep4096x64_b256` reports (profiles/r04_deep4096x64.json)."""
+    import json
+    import time
+    import bench
+    from zkdl_amd.capi import Transcript
+    dims, batch = bench.WORKLOADS["deep4096x64_b256"]
+    t0 = time.perf_counter()
+    wl = bench.Workload(zk, dims, batch, seed=12)
+    zk.sync()
+    t_setup = time.perf_counter() - t0
+    L = len(wl.shapes)
+    assert L == 64 and all(s["n_gens"] == 4096 and s["m"] == 4096 for s in wl.shapes)
+    # every zkFC slice; the zkReLU slices of the first, a middle and the last hidden layer (each materialises that layer's 1.5 GB of
+    # one-field-element-per-bit tensors for the check; the other 60 are covered by the whole-transcript invariance checks below)
+    fr, aff, inf = check_workload(zk, wl, relu_layers={0, L // 2, L - 2}, fc_layers=set(range(L)))
+    assert fr.shape[0] == sum(3 * 12 + 4 for _ in range(L)) + (L - 1) * (3 * 25 + 1 + 32 + 3 * 24 + 1 + 16 + 3 * 20 + 2) and aff.shape[0] == L * (3 * 12 + 2)
+    # timing of the synchronous loop (the reference's own definition of its metric, demo.cu:124-140)
+    tr = Transcript(zk)
+    wl.prove(wl.challenges(0), tr)
+    tr.flush()
+    zk.sync()
+    t0 = time.perf_counter()
+    for st in range(3):
+        wl.prove(wl.challenges(st), tr)
+        tr.flush()
+    zk.sync()
+    ms = (time.perf_counter() - t0) * 1e3 / 3
+    assert ms / batch < 100.0
+    tr.close()
+    # oracle parity at width 4096, batch 256: zkFC 63 (opens Y_hat), zkReLU 62, zkFC 62
+    calls = [("fc", L - 1), ("relu", L - 2), ("fc", L - 2)]
+    t0 = time.perf_counter()
+    _, checked = bench.cpu_baseline_check_only(zk, wl, calls, (wl.challenges(0), fr, aff, inf))
+    t_oracle = time.perf_counter() - t0
+    assert checked["ok"], checked
+    assert checked["calls"] == ["zkFC63", "zkFC62", "zkReLU62"]
+    assert checked["g1"] == 2 * (3 * 12 + 2) and checked["fr"] == 2 * (3 * 12 + 4) + (3 * 25 + 1 + 32 + 3 * 24 + 1 + 16 + 3 * 20 + 2)
+    keep = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(keep):
+        with open(os.path.join(keep, "deep4096x64_test.json"), "w") as f:
+            json.dump({"workload": "deep4096x64_b256", "dims": "4096 x 65", "batch": batch, "setup_s": t_setup, "synchronous_ms_per_proof": ms,
+                       "ms_per_example": ms / batch, "transcript": [int(fr.shape[0]), int(aff.shape[0])], "layers_verified": {"zkFC": L, "zkReLU": 3},
+                       "parity_checked": checked, "oracle_s": t_oracle}, f, indent=1)

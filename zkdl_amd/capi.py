@@ -8,6 +8,7 @@ G1 Jacobian (n, 36) -- byte-compatible with the reference's Fr_t / G1Affine_t / 
 """
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -90,6 +91,19 @@ def load_library():
 
 
 def _load_library():
+    # ZKDL_AMD_LIB=<path>: another build of the SAME library (tools/ab_phases.sh points it at lib/variants/lib_exp.so, the -DZKDL_EXPERIMENTS build,
+    # instead of swapping files); never the oracle, never a CPU fallback
+    path = os.environ.get("ZKDL_AMD_LIB") or LIB_PATH
+    if path != LIB_PATH:
+        if not os.path.exists(path):
+            raise RuntimeError("ZKDL_AMD_LIB=%s does not exist" % path)
+        sys.stderr.write("zkdl_amd: loading %s instead of the shipping library\n" % path)
+        lib = ctypes.CDLL(path)
+        for name, restype, argtypes in _header_prototypes():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        return lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libzkdl_amd.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                            "there is no CPU fallback for the proving path")

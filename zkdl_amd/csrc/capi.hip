@@ -136,13 +136,13 @@ int zk_ctx_create(int device, zk_ctx** out) {
   ctx->main_stream = ctx->stream;
   {
     int nl = 8;
-    if (const char* e = getenv("ZKDL_LANES")) nl = atoi(e);
+    if (const char* e = experiment_env("ZKDL_LANES")) nl = atoi(e);
     if (nl < 0) nl = 0;
     if (nl > 16) nl = 16;
     ctx->lanes.resize((size_t)nl);
     // ZKDL_LANE_PRIO (experiment): 1 = worker lanes at the highest stream priority (their launches are small and latency-bound; the G1 stream carries the bulk)
     int lane_prio = 0;
-    if (const char* e = getenv("ZKDL_LANE_PRIO")) lane_prio = atoi(e);
+    if (const char* e = experiment_env("ZKDL_LANE_PRIO")) lane_prio = atoi(e);
     int lp_least = 0, lp_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&lp_least, &lp_greatest);
     for (auto& l : ctx->lanes)
@@ -154,13 +154,13 @@ int zk_ctx_create(int device, zk_ctx** out) {
     // G1 stream priority: the MSM batch is bulk work that should fill the gaps the latency-bound Fr chains
     // leave, not delay them (ZKDL_G1_PRIO = -1 low, 0 normal (default; low priority with more than the default number of hardware queues stalled the pipeline), 1 high)
     int g1_prio = 0;
-    if (const char* e = getenv("ZKDL_G1_PRIO")) g1_prio = atoi(e);
+    if (const char* e = experiment_env("ZKDL_G1_PRIO")) g1_prio = atoi(e);
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     int prio = g1_prio < 0 ? least : g1_prio > 0 ? greatest : (least + greatest) / 2;
     {
       int ng = 2;  // a sealed proof's G1 phase is ~7 ms long (derived round commitments on the 28-bit-limb field); 3 or 4 streams measure slower
-      if (const char* e = getenv("ZKDL_G1_STREAMS")) ng = atoi(e);
+      if (const char* e = experiment_env("ZKDL_G1_STREAMS")) ng = atoi(e);
       ng = ng < 0 ? 0 : ng > 8 ? 8 : ng;
       ctx->g1_lanes.resize((size_t)ng);
       // The G1 streams are confined to every other compute unit: the bulk MSM accumulation (a whole-chip launch
@@ -168,7 +168,7 @@ int zk_ctx_create(int device, zk_ctx** out) {
       // the 18M MLP: 7.06 -> 6.77 ms/proof at batch 256, 5.68 -> 4.18 at batch 1; neutral on the width-4096 model.
       // Irregular masks (45 %, 55 %, 60 %) were much slower than none.  ZKDL_G1_CU_PERCENT=100 turns it off.
       int cu_pct = 50;
-      if (const char* e = getenv("ZKDL_G1_CU_PERCENT")) cu_pct = atoi(e);
+      if (const char* e = experiment_env("ZKDL_G1_CU_PERCENT")) cu_pct = atoi(e);
       std::vector<uint32_t> cu_mask;
       if (cu_pct > 0 && cu_pct < 100) {
         hipDeviceProp_t prop;
@@ -212,7 +212,7 @@ int zk_ctx_create(int device, zk_ctx** out) {
   }
   {
     int nt = 0;  // ZKDL_TAIL_STREAMS: streams for the latency-bound tail of a sealed proof's G1 phase (0 = keep it on the G1 stream)
-    if (const char* e = getenv("ZKDL_TAIL_STREAMS")) nt = atoi(e);
+    if (const char* e = experiment_env("ZKDL_TAIL_STREAMS")) nt = atoi(e);
     nt = nt < 0 ? 0 : nt > 8 ? 8 : nt;
     if (ctx->g1_lanes.empty()) nt = 0;
     ctx->tail_lanes.resize((size_t)nt);

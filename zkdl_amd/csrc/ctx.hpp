@@ -247,8 +247,12 @@ namespace zk {
 // garbage) exist only in builds made with `make EXPERIMENTS=1` (-DZKDL_EXPERIMENTS); the shipping library ignores the variables.
 #ifdef ZKDL_EXPERIMENTS
 inline bool experiment_on(const char* name) { return getenv(name) != nullptr; }
+inline const char* experiment_env(const char* name) { return getenv(name); }
 #else
 constexpr bool experiment_on(const char*) { return false; }
+// A/B switches that select between value-preserving code paths or scheduling knobs (stream counts, priorities, kernel variants): the shipping
+// library always takes the default; tools/ab_*.sh run the EXPERIMENTS build (ZKDL_AMD_LIB=zkdl_amd/lib/variants/lib_exp.so)
+constexpr const char* experiment_env(const char*) { return nullptr; }
 #endif
 
 #define ZK_TRY(expr)              \

@@ -771,7 +771,7 @@ static int relu_prove_body(zk_ctx* ctx, const zk_relu* relu, const Fr* x, const 
     out += 16;
   }
   {
-    static const int hp_group = [] { const char* e = getenv("ZKDL_HP_GROUP"); return e ? atoi(e) : (int)REC_GROUP_FC_OPEN; }();  // A/B: which stream the Hadamard chains share
+    static const int hp_group = [] { const char* e = experiment_env("ZKDL_HP_GROUP"); return e ? atoi(e) : (int)REC_GROUP_FC_OPEN; }();  // A/B: which stream the Hadamard chains share
     rec_split(ctx, (uint32_t)hp_group);
   }
   ZK_TRY(sumcheck_hp_dev(ctx, x, relu->sign, n, c + offs[5], c + offs[6], k, out, ctx->relu_packed ? relu->sign_packed : nullptr));

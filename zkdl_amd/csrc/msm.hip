@@ -789,6 +789,7 @@ __device__ __forceinline__ void msmf_accum_body(const FullJob* __restrict__ jobs
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_msmf_accum(const FullJob* __restrict__ jobs, uint32_t c, RecodeK K, G1X* __restrict__ partial) {
   msmf_accum_body<true, 1>(jobs, c, K, partial);
 }
+#ifdef ZKDL_EXPERIMENTS
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_msmf_accum_v1(const FullJob* __restrict__ jobs, uint32_t c, RecodeK K, G1X* __restrict__ partial) {
   msmf_accum_body<true, 2>(jobs, c, K, partial);
 }
@@ -798,6 +799,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_msmf_accum_v3(const FullJob* __restrict__ jobs, uint32_t c, RecodeK K, G1X* __restrict__ partial) {
   msmf_accum_body<false, 2>(jobs, c, K, partial);
 }
+#endif
 __global__ void __launch_bounds__(256) k_msmf_reduce(const FullJob* __restrict__ jobs, const G1X* __restrict__ partial) {
   __shared__ G1X sm[4];
   const FullJob job = jobs[blockIdx.x];
@@ -881,12 +883,15 @@ static int msm_run_full_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs) 
     else ZK_TRY(host_to_dev(ctx, djobs.get(), jobs.data(), bytes));
   }
   ZK_ALLOC(ctx, partial, G1X, parts);
-  static const int variant = [] { const char* e = getenv("ZKDL_FT_VARIANT"); return e ? atoi(e) : 0; }();
   const dim3 grid((max_lanes + 63) / 64, nj);
+#ifdef ZKDL_EXPERIMENTS
+  static const int variant = [] { const char* e = getenv("ZKDL_FT_VARIANT"); return e ? atoi(e) : 0; }();
   if (variant == 1) ZK_LAUNCH(ctx, "msm_table_accum", 100ull * items_all, k_msmf_accum_v1, grid, dim3(64), 0, (const FullJob*)djobs.get(), c, K, partial.get());
   else if (variant == 2) ZK_LAUNCH(ctx, "msm_table_accum", 100ull * items_all, k_msmf_accum_v2, grid, dim3(64), 0, (const FullJob*)djobs.get(), c, K, partial.get());
   else if (variant == 3) ZK_LAUNCH(ctx, "msm_table_accum", 100ull * items_all, k_msmf_accum_v3, grid, dim3(64), 0, (const FullJob*)djobs.get(), c, K, partial.get());
-  else ZK_LAUNCH(ctx, "msm_table_accum", 100ull * items_all, k_msmf_accum, grid, dim3(64), 0, (const FullJob*)djobs.get(), c, K, partial.get());
+  else
+#endif
+  ZK_LAUNCH(ctx, "msm_table_accum", 100ull * items_all, k_msmf_accum, grid, dim3(64), 0, (const FullJob*)djobs.get(), c, K, partial.get());
   ZK_LAUNCH(ctx, "msm_table_sum", (uint64_t)sizeof(G1X) * parts, k_msmf_reduce, dim3(nj), dim3(256), 0, (const FullJob*)djobs.get(), (const G1X*)partial.get());
   return ZK_OK;
 }

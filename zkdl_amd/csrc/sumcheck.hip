@@ -71,11 +71,14 @@ __device__ __forceinline__ void k_sc_prep(uint32_t zk_nblk, const Fr* __restrict
 //   fold[r0 + j]  : fold challenge of round r0 + j (device memory)
 //   Aj / cj       : low weight table and its width for round r0 + j ; B the fixed high table
 //   partial[blk*3R + 3j + q], j < R, q < 3 ; prev_* : the previous launch's partials (3*prev_R per block)
+// (the multi-round form and the 32-bit-limb single round never beat k_sc_round29 on MI355X: they are compiled into the EXPERIMENTS build only)
+#ifdef ZKDL_EXPERIMENTS
 static uint32_t sc_multi_threshold(int R) {
   static const uint32_t t3 = [] { const char* e = getenv("ZKDL_SC_R3_MIN"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xffffffffu; }();
   static const uint32_t t2 = [] { const char* e = getenv("ZKDL_SC_R2_MIN"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xffffffffu; }();
   return R == 3 ? t3 : t2;
 }
+#endif
 
 struct ScLevels {
   const Fr* A[3];
@@ -500,7 +503,7 @@ __device__ __forceinline__ void k_sc_tail(uint32_t zk_nblk, const Fr* __restrict
 }
 
 static bool sc29_enabled() {
-  static const bool off = getenv("ZKDL_SC_OLD") != nullptr;  // A/B switch: the 32-bit-limb rounds
+  static const bool off = experiment_on("ZKDL_SC_OLD");  // A/B switch (EXPERIMENTS build): the 32-bit-limb rounds
   return !off;
 }
 template <int MODE>
@@ -525,7 +528,7 @@ static int run_sumcheck(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n,
       // fixed split: every big round r (< nbig) needs c_r = s - 1 - r >= 0
       // (with the 29-bit-limb rounds a workgroup covers 2^11 pairs: a wide low table keeps the high weight constant per workgroup)
       s = nbig;
-      static const bool wide_split = getenv("ZKDL_SC29_NARROW") == nullptr;  // A/B switch: keep the split at the number of big rounds (no factored weights then)
+      static const bool wide_split = !experiment_on("ZKDL_SC29_NARROW");  // A/B switch (EXPERIMENTS build): keep the split at the number of big rounds (no factored weights then)
       if (sc29_enabled() && wide_split && k >= 6 && k - 6 > s) s = k - 6;
       if (s > k) s = k;
       if (!tabA.alloc(ctx, (size_t)1 << s) || !tabB.alloc(ctx, (size_t)1 << (k - s))) return ctx->fail(ZK_ERR_ALLOC, "device allocation failed: sumcheck weights");
@@ -550,9 +553,11 @@ static int run_sumcheck(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n,
     // MI355X it never beat one round per launch on this workload (the rounds are VALU-bound, not HBM-bound),
     // so it is off unless ZKDL_SC_R2_MIN / ZKDL_SC_R3_MIN set a size threshold.
     uint32_t R = 1;
+#ifdef ZKDL_EXPERIMENTS
     if (sz >= sc_multi_threshold(3)) R = 3;
     else if (sz >= sc_multi_threshold(2)) R = 2;
     if (R > nbig - r) R = nbig - r;
+#endif
     uint32_t osz = sz;
     for (uint32_t j = 0; j < R; j++) osz = (osz + 1) / 2;
     ScLevels lv;
@@ -564,14 +569,14 @@ static int run_sumcheck(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n,
         lv.A[j] = tabA.get() + ((1u << s) - (1u << (s - (r + j))));
       }
     }
-    static const bool no_fact = getenv("ZKDL_SC_NOFACT") != nullptr;  // A/B switch for the factored-weight path
+    static const bool no_fact = experiment_on("ZKDL_SC_NOFACT");  // A/B switch (EXPERIMENTS build) for the factored-weight path
     if (no_fact && R == 1) lv.c[2] = 0xffu;
     uint32_t grid = stream_grid(osz, 256, SC_MAX_BLOCKS);
     Fr* ao = a_slots[launch & 1];
     Fr* bo = b_slots[launch & 1];
     Fr* part = partial.get() + (launch & 1) * 9 * SC_MAX_BLOCKS;
     uint64_t bytes = (two ? 2ull : 1ull) * 32ull * ((uint64_t)sz + osz);
-    static const bool no_hp0 = getenv("ZKDL_NO_HP0") != nullptr;  // A/B switch
+    static const bool no_hp0 = experiment_on("ZKDL_NO_HP0");  // A/B switch (EXPERIMENTS build)
     if (MODE == SC_HP && b_bits && r == 0 && !no_hp0) {  // 0/1 second operand, one byte per element: round 0 without its products by b
       ZK_LAUNCHB(ctx, tag, 32ull * ((uint64_t)sz + 2ull * osz) + sz, 256, k_sc_round_hp0, dim3(grid), 0, a, b_bits, ao, bo, fold_d, lv, (const Fr*)tabB.get(), sz, osz, part);
       prev_partial = part;
@@ -588,13 +593,16 @@ static int run_sumcheck(zk_ctx* ctx, const Fr* a_in, const Fr* b_in, uint32_t n,
 #define ZK_SC_LAUNCH(RR)                                                                                                                                   \
   ZK_LAUNCHB(ctx, tag, bytes, 256, (k_sc_round<MODE, RR>), dim3(grid), 0, a, b, ao, bo, fold_d + r, lv, (const Fr*)tabB.get(), sz, osz, part, prev_partial, \
             prev_blocks, prev_cols, prev_dst)
+#ifdef ZKDL_EXPERIMENTS
     if (R == 3) ZK_SC_LAUNCH(3);
     else if (R == 2) ZK_SC_LAUNCH(2);
     else if (!sc29_enabled()) ZK_SC_LAUNCH(1);
-    else {
+    else
+#endif
+    {
       // SC29_PPT pairs per lane, but at least 64 workgroups while each still gets a full 256 pairs (the factored weights
       // need 2^(k-s) = 64 of them)
-      static const uint32_t ppt = [] { const char* e = getenv("ZKDL_SC29_PPT"); uint32_t v = e ? (uint32_t)strtoul(e, nullptr, 0) : SC29_PPT; return v ? v : 1u; }();
+      static const uint32_t ppt = [] { const char* e = experiment_env("ZKDL_SC29_PPT"); uint32_t v = e ? (uint32_t)strtoul(e, nullptr, 0) : SC29_PPT; return v ? v : 1u; }();
       uint32_t g29 = stream_grid((osz + ppt - 1) / ppt, 256, SC_MAX_BLOCKS);
       if (g29 < 64) g29 = osz / 256 >= 64 ? 64 : stream_grid(osz, 256, 64);
       grid = g29;
