@@ -1,6 +1,7 @@
 // Host-side driver for tests/test_fq28.py: the 28-bit-limb base-field arithmetic (zkdl_amd/csrc/fq28.hpp) and the Jacobian group law on
 // it (g1q.hpp), compiled for the CPU, on operands read from stdin (hex, the library's 12 x 32-bit Montgomery form); results canonical.
-//   mul a b      -> to_fp(from_fp(a) * from_fp(b))            sqr a -> ...      inv a -> to_fp(inv(from_fp(a)))
+//   mul a b      -> to_fp(from_fp(a) * from_fp(b))            sqr a -> ...      inv a -> to_fp(inv(from_fp(a)))   (invf: the Fermat chain)
+//   inv32 a / inv32f a -> fp_inv (binary GCD, fpinv.hpp) / fp_inv_fermat on the 12 x 32-bit form;  invint y -> y^-1 mod p of the plain integer
 //   lazy a b     -> to_fp( (a + b) * norm(a - b + 3p) )      (unreduced operands)
 //   dbl x y z / add x1 y1 z1 x2 y2 z2 / mul4 x y z k(hex, < 2^128)  -> canonical affine x y (Jacobian in, the library's form)
 #include <cstdio>
@@ -29,8 +30,7 @@ static G1J point() {
   return p;
 }
 static void show_point(const G1Q& q) {
-  Fq tab[16];
-  G1J c = g1q_canonical(q, tab, 1);
+  G1J c = g1q_canonical(q);
   show(c.x); show(c.y); show(c.z);
 }
 int main() {
@@ -44,8 +44,14 @@ int main() {
     } else if (op == "sqr" || op == "inv") {
       std::string a; std::cin >> a;
       Fq x = fq_from_fp(parse(a));
+      show(fq_to_fp(op == "sqr" ? fq_sqr(x) : fq_inv(x)));
+    } else if (op == "invf") {       // the Fermat chains (a^(p-2)): the independent cross-check of the binary-GCD inverse
+      std::string a; std::cin >> a;
       Fq tab[16];
-      show(fq_to_fp(op == "sqr" ? fq_sqr(x) : fq_inv(x, tab, 1)));
+      show(fq_to_fp(fq_inv_fermat(fq_from_fp(parse(a)), tab, 1)));
+    } else if (op == "inv32" || op == "inv32f" || op == "invint") {   // 12 x 32-bit Montgomery form: fp_inv (binary GCD) / fp_inv_fermat; invint: plain integer inverse
+      std::string a; std::cin >> a;
+      show(op == "inv32" ? fp_inv(parse(a)) : op == "inv32f" ? fp_inv_fermat(parse(a)) : fp_inv_int(parse(a)));
     } else if (op == "dbl") {
       show_point(g1q_double(g1q_from_jacobian(point())));
     } else if (op == "add") {

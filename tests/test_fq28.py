@@ -55,6 +55,23 @@ def test_field_products_inverse_and_lazy_operands(exe):
     assert got == [mont(pow(x, -1, P)) for x in nz]
 
 
+def test_binary_gcd_inverse_equals_the_fermat_chain_and_python(exe):
+    """fpinv.hpp (optimised binary GCD: 25 groups of 31 halving steps on 64-bit approximations) against pow(x, -1, p) and against the Fermat
+    chains it replaced, in both limb forms; 0 -> 0; operands that stress the approximations (tiny values, values just below p, powers of two,
+    a and b agreeing in their top bits)."""
+    rng = random.Random(31)
+    edge = [0, 1, 2, 3, P - 1, P - 2, P - 3, (P - 1) // 2, (P + 1) // 2, (1 << 31) - 1, 1 << 31, (1 << 31) + 1, (1 << 62) - 1, 1 << 62, (1 << 64) - 1, 1 << 64,
+            (1 << 64) + 1, (1 << 96) - 1, 1 << 380, (1 << 380) + 1, P - (1 << 32), P - (1 << 64) + 1, P >> 1, P >> 2, P >> 33, (P >> 33) + 1]
+    xs = edge + [rng.randrange(P) for _ in range(700)] + [rng.randrange(1 << rng.randrange(1, 381)) for _ in range(300)]
+    want = [pow(x, -1, P) if x else 0 for x in xs]
+    assert run(exe, ["invint %x" % x for x in xs]) == want                                   # plain integers
+    assert run(exe, ["inv32 %x" % mont(x) for x in xs]) == [mont(w) for w in want]              # Montgomery form in, Montgomery form out
+    assert run(exe, ["inv %x" % mont(x) for x in xs]) == [mont(w) for w in want]                # through the 28-bit-limb form
+    sub = xs[:60]
+    assert run(exe, ["inv32f %x" % mont(x) for x in sub]) == [mont(w) for w in want[:60]]       # the chains it replaced agree
+    assert run(exe, ["invf %x" % mont(x) for x in sub if x]) == [mont(pow(x, -1, P)) for x in sub if x]
+
+
 # ---- affine reference arithmetic
 def ec_add(p1, p2):
     if p1 is None:

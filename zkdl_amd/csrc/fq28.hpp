@@ -22,6 +22,7 @@
 //   the parity tests compare.
 #pragma once
 #include "field.hpp"
+#include "fpinv.hpp"
 
 namespace zk {
 
@@ -300,11 +301,14 @@ ZK_HD Fq fq_from_fp(const Fp& a) {
   for (int i = 0; i < 14; i++) c.v[i] = c400[i];
   return fq_mul(fq_unpack(a), c);  // a 2^400 / 2^392 = a 2^8
 }
-// a^(p-2), a normalised and < 2^5 p (Fermat inverse; backs the affine-canonical form, see field.hpp:fp_inv), by 4-bit fixed windows:
+// the inverse of a bounded n-form value (normalised, < 2^5 p), n-form, < 2p:  through the canonical 12 x 32-bit form and the binary GCD of
+// fpinv.hpp (two conversion products + ~33 k scalar-width instructions, against the ~290 k of the Fermat chain below).  0 -> 0.
+ZK_HD Fq fq_inv(const Fq& a) { return fq_from_fp(fp_inv_bingcd(fq_to_fp(a))); }
+// a^(p-2), a normalised and < 2^5 p (Fermat inverse; the independent cross-check of fq_inv; backs the affine-canonical form, see field.hpp:fp_inv), by 4-bit fixed windows:
 // a^1 .. a^15 in `tab` (entry i at tab[i * stride]: the caller's scratch -- LDS on the device, where every lane of a wave reads the same
 // entry index because the exponent is a constant), then 95 x (four squarings + one table product): 380 + 91 + 14 products instead of the
 // 381 + 229 of the bitwise ladder.  The inversion is ONE lane's latency chain behind every proof's G1 phase.
-ZK_HD Fq fq_inv(const Fq& a, Fq* tab, int stride) {
+ZK_HD Fq fq_inv_fermat(const Fq& a, Fq* tab, int stride) {
   tab[1 * stride] = a;
 #pragma unroll 1
   for (int i = 2; i < 16; i++) tab[i * stride] = fq_mul(tab[(i - 1) * stride], a);

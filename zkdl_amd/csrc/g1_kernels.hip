@@ -8,6 +8,7 @@
 // (G1NumThread = 64, g1-tensor.cuh:11), which also makes the sum tree below identical to its.
 #include "ctx.hpp"
 #include "dev_util.hpp"
+#include "fpinv.hpp"
 
 namespace zk {
 

@@ -78,10 +78,10 @@ ZK_HD G1Q g1q_neg(const G1Q& a) {
   r.y = fq_norm(fq_sub<20>(fq_zero(), a.y));  // < 20
   return r;
 }
-// (x, y, 1) canonical, fully reduced, in the library's form; infinity as {0, ONE, 0}.  tab / stride: 16 entries of scratch for fq_inv
-ZK_HD G1J g1q_canonical(const G1Q& a, Fq* tab, int stride) {
+// (x, y, 1) canonical, fully reduced, in the library's form; infinity as {0, ONE, 0}
+ZK_HD G1J g1q_canonical(const G1Q& a) {
   if (g1q_is_zero(a)) return g1_zero();
-  const Fq zi = fq_inv(a.z, tab, stride), zi2 = fq_sqr(zi);
+  const Fq zi = fq_inv(a.z), zi2 = fq_sqr(zi);
   G1J r;
   r.x = fq_to_fp(fq_mul(a.x, zi2));
   r.y = fq_to_fp(fq_mul(a.y, fq_mul(zi2, zi)));

@@ -557,12 +557,11 @@ __global__ void __launch_bounds__(64) k_msm_weighted(const MsmJob* __restrict__ 
 
 // canonical form in place: affine x, y with Z = ONE; infinity as {0, ONE, 0}
 __global__ void __launch_bounds__(64) k_g1_canonicalise(G1J* __restrict__ pts, uint32_t n) {
-  __shared__ Fq wtab[16 * 64];  // a^1 .. a^15 of every lane's inversion (fq_inv): 56 KB
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   G1J p = pts[i];
   if (!l_is_zero(p.z) && l_eq(p.z, fp_one())) return;
-  pts[i] = g1q_canonical(g1q_from_jacobian(p), wtab + threadIdx.x, 64);  // the inversion's ~485 dependent products in the 28-bit-limb form (g1q.hpp)
+  pts[i] = g1q_canonical(g1q_from_jacobian(p));  // one inversion per point: the binary GCD of fpinv.hpp (no field products on the chain)
 }
 int g1_canonicalise_dev(zk_ctx* ctx, G1J* pts, uint32_t n) {
   if (n) ZK_LAUNCH(ctx, "g1_canonicalise", 288ull * n, k_g1_canonicalise, dim3((n + 63) / 64), dim3(64), 0, pts, n);
@@ -571,7 +570,6 @@ int g1_canonicalise_dev(zk_ctx* ctx, G1J* pts, uint32_t n) {
 
 // the same over up to 8 ranges in ONE launch (the G1 phases of several proofs run as one batch: the inversion's latency is paid once)
 __global__ void __launch_bounds__(64) k_g1_canonicalise_multi(CanonRanges r) {
-  __shared__ Fq wtab[16 * 64];
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   G1J* pts = nullptr;
   for (uint32_t q = 0; q < r.cnt; q++) {
@@ -582,7 +580,7 @@ __global__ void __launch_bounds__(64) k_g1_canonicalise_multi(CanonRanges r) {
   if (!pts) return;
   G1J p = pts[i];
   if (!l_is_zero(p.z) && l_eq(p.z, fp_one())) return;
-  pts[i] = g1q_canonical(g1q_from_jacobian(p), wtab + threadIdx.x, 64);
+  pts[i] = g1q_canonical(g1q_from_jacobian(p));
 }
 int g1_canonicalise_multi_dev(zk_ctx* ctx, const CanonRanges& r) {
   uint32_t n = 0;
@@ -624,7 +622,6 @@ struct FullJob {
 static constexpr uint32_t FT_SEG = 64;  // points put into affine form per shared inversion
 __global__ void __launch_bounds__(64) k_fulltable_build(const G1A* __restrict__ win, const uint8_t* __restrict__ inf, uint32_t n, uint32_t W, uint32_t half,
                                                          G1AE* __restrict__ out, G1X* __restrict__ scratch, Fq* __restrict__ prefix) {
-  __shared__ Fq wtab[16 * 64];
   const uint32_t row = blockIdx.x * 64u + threadIdx.x;  // row = j * W + w
   if (row >= n * W) return;
   const uint32_t j = row / W, w = row % W;
@@ -645,7 +642,7 @@ __global__ void __launch_bounds__(64) k_fulltable_build(const G1A* __restrict__ 
       run = fq_mul(run, fq_mul(acc.zz, acc.zzz));
       pr[i] = run;
     }
-    Fq inv = fq_inv(fq_norm(run), wtab + threadIdx.x, 64);
+    Fq inv = fq_inv(fq_norm(run));
 #pragma unroll 1
     for (uint32_t ii = cnt; ii > 0; ii--) {
       const uint32_t i = ii - 1;

@@ -206,7 +206,13 @@ inline std::ostream& operator<<(std::ostream& os, const FrTensor& A) {   // fr-t
 // recurses launch by launch; here each is one call into the C ABI (same field elements).
 inline Fr_t Fr_me(const FrTensor& t, std::vector<Fr_t>::const_iterator begin, std::vector<Fr_t>::const_iterator end) {
   if (begin >= end) return t(0);                                    // fr-tensor.cu:414
-  return t(std::vector<Fr_t>(begin, end));
+  // fewer challenges than log2(size): the recursion folds adjacent pairs k times and returns element 0, which depends on the first 2^k entries only
+  const size_t k = (size_t)(end - begin);
+  const uint n = (k < 32 && t.size > (1u << k)) ? (1u << k) : t.size;
+  std::vector<Fr_t> u(begin, end);
+  Fr_t out;
+  zkdl::check(zk_fr_me(zkdl::ctx(), t.data(), n, u.data(), (uint32_t)u.size(), &out));
+  return out;
 }
 inline FrTensor Fr_partial_me(const FrTensor& t, std::vector<Fr_t>::const_iterator begin, std::vector<Fr_t>::const_iterator end, uint window_size) {
   if (begin >= end) return t;                                       // fr-tensor.cu:436 (App. D-3: no challenges = the identity)
@@ -443,7 +449,12 @@ class G1TensorJacobian : public G1Tensor {
 // g1-tensor.cuh:170, g1-tensor.cu:477-484
 inline G1Jacobian_t G1_me(const G1TensorJacobian& t, std::vector<Fr_t>::const_iterator begin, std::vector<Fr_t>::const_iterator end) {
   if (begin >= end) return t(0);
-  return t(std::vector<Fr_t>(begin, end));
+  const size_t k = (size_t)(end - begin);
+  const uint n = (k < 32 && t.size > (1u << k)) ? (1u << k) : t.size;   // as Fr_me: element 0 after k folds of adjacent pairs
+  std::vector<Fr_t> u(begin, end);
+  G1Jacobian_t out;
+  zkdl::check(zk_g1_me(zkdl::ctx(), t.data(), n, u.data(), (uint32_t)u.size(), &out));
+  return out;
 }
 
 // ------------------------------------------------------------------ Commitment (commitment.cuh:8-23)
