@@ -167,7 +167,7 @@ static int contract(zk_ctx* ctx, const Fr* t, uint32_t n, const Fr* u_d, uint32_
   ZK_ALLOC(ctx, E, Fr, M);
   ZK_TRY(eq_table(ctx, u_d, c, E.get()));
   uint64_t bytes = 32ull * ((uint64_t)n + (uint64_t)H * W);
-  if (W == 1 && M >= 64) {
+  if (W == 1 && M >= 128) {
     ZK_LAUNCHB(ctx, "fr_contract", bytes, 256, k_dot_block, dim3((H + 3) / 4), 0, t, n, (const Fr*)E.get(), M, out, H);
   } else {
     uint32_t total = H * W;
@@ -193,18 +193,60 @@ __device__ __forceinline__ Acc9 acc9_zero() {
   for (int i = 0; i < 9; i++) a.v[i] = 0;
   return a;
 }
-// a += (q < 0 ? r - e : e) * |q|
-__device__ __forceinline__ void acc9_mac(Acc9& a, const Fr& e, int32_t q) {
-  const uint32_t mag = (uint32_t)(q < 0 ? -q : q);
-  const Fr x = q < 0 ? fr_neg(e) : e;
+// T = lo + hi * 2^256  ->  T mod r:  lo < 2^256 < 5r by repeated subtraction, hi * 2^256 = mont(hi)
+__device__ __forceinline__ Fr acc9_reduce(const Acc9& a) {
+  Fr lo;
+#pragma unroll
+  for (int i = 0; i < 8; i++) lo.v[i] = a.v[i];
+#pragma unroll
+  for (int it = 0; it < 4; it++) lo = f_reduce_once<FrP>(lo);
+  Fr hi = fr_zero();
+  hi.v[0] = a.v[8];
+  return fr_add(lo, fr_mont(hi));
+}
+// ---- the int16 contractions, version 2: no per-element sign handling, no carries, and the weight table kept in registers.
+//   * signs: with u = w + 2^15 (an unsigned 16-bit number),  sum_m E[m] w_m = sum_m E[m] u_m - 2^15 T,  T = sum_m E[m] -- one integer per
+//     launch shape (the same for every output).  The correction enters as the non-negative constant  C = 2^15 (M r - T)  (a multiple of r
+//     more), so an output is  (sum_m E[m] u_m + C) mod r.
+//   * carries: E[m]_i * u < 2^48, so a limb's products are summed as they are in a 64-bit COLUMN (one v_mad_u64_u32 each; <= 2^16 terms);
+//     columns add across lanes as plain integers and are carried once per output.
+//   * k_dot_q16: a wave takes DOT_ROWS consecutive rows and every lane two adjacent columns per step, whose table entries stay in registers
+//     for all the rows: one dword of weights and 16 MACs per row and step, the 32-byte table entries read once per DOT_ROWS rows.
+// ~10 instructions per weight instead of ~50 (conditional negation of the table entry + a carry chain per limb).
+struct Col8 {
+  uint64_t c[8];
+};
+__device__ __forceinline__ void col8_zero(Col8& a) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) a.c[i] = 0;
+}
+__device__ __forceinline__ void col8_mac(Col8& a, const Fr& e, uint32_t u) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) a.c[i] += (uint64_t)e.v[i] * u;
+}
+// all lanes receive the wave's column sums
+__device__ __forceinline__ void col8_wave_sum(Col8& a) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const uint32_t lo = __shfl_xor((uint32_t)a.c[i], off, 64), hi = __shfl_xor((uint32_t)(a.c[i] >> 32), off, 64);
+      a.c[i] += ((uint64_t)hi << 32) | lo;
+    }
+  }
+}
+// columns (sum < 2^288) -> the 9-limb integer
+__device__ __forceinline__ Acc9 col8_carry(const Col8& a) {
+  Acc9 r;
   uint64_t carry = 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    uint64_t t = (uint64_t)x.v[i] * mag + a.v[i] + carry;
-    a.v[i] = (uint32_t)t;
-    carry = t >> 32;
+    const uint64_t lo = (a.c[i] & 0xffffffffull) + (carry & 0xffffffffull);
+    r.v[i] = (uint32_t)lo;
+    carry = (a.c[i] >> 32) + (carry >> 32) + (lo >> 32);
   }
-  a.v[8] += (uint32_t)carry;
+  r.v[8] = (uint32_t)carry;
+  return r;
 }
 __device__ __forceinline__ Acc9 acc9_add(const Acc9& a, const Acc9& b) {
   Acc9 r;
@@ -217,77 +259,88 @@ __device__ __forceinline__ Acc9 acc9_add(const Acc9& a, const Acc9& b) {
   }
   return r;
 }
-// T = lo + hi * 2^256  ->  T mod r:  lo < 2^256 < 5r by repeated subtraction, hi * 2^256 = mont(hi)
-__device__ __forceinline__ Fr acc9_reduce(const Acc9& a) {
-  Fr lo;
+// C = 2^15 (M r - T), T = the integer sum of the M table entries (< M r), M = 2^c
+__device__ __forceinline__ Acc9 q16_offset_const(const Acc9& T, uint32_t c) {
+  Acc9 mr;  // r << c
 #pragma unroll
-  for (int i = 0; i < 8; i++) lo.v[i] = a.v[i];
-#pragma unroll
-  for (int it = 0; it < 4; it++) lo = f_reduce_once<FrP>(lo);
-  Fr hi = fr_zero();
-  hi.v[0] = a.v[8];
-  return fr_add(lo, fr_mont(hi));
-}
-__device__ __forceinline__ Acc9 wave_sum_acc9(Acc9 x) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    Acc9 y;
-#pragma unroll
-    for (int i = 0; i < 9; i++) y.v[i] = __shfl_down(x.v[i], off, 64);
-    x = acc9_add(x, y);
+  for (int i = 0; i < 9; i++) {
+    const uint32_t lo = i < 8 ? FrP::P(i) : 0u, below = i ? FrP::P(i - 1) : 0u;
+    mr.v[i] = c ? ((lo << c) | (below >> (32 - c))) : lo;
   }
-  return x;
+  Acc9 d;
+  uint32_t bw = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    uint32_t bo;
+    d.v[i] = __builtin_subc(mr.v[i], T.v[i], bw, &bo);
+    bw = bo;
+  }
+  Acc9 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = (d.v[i] << 15) | (i ? d.v[i - 1] >> 17 : 0u);
+  return r;
 }
-// out[h*W + w] = sum_{m<M} E[m] * q[(h*M + m)*W + w]; one thread per output
-__device__ __forceinline__ void k_colsum_q16(uint32_t zk_nblk, const int16_t* __restrict__ q, uint32_t n, const Fr* __restrict__ E, uint32_t M, uint32_t W,
+// out[h*W + w] = sum_{m<M} E[m] * q[(h*M + m)*W + w]; one thread per output; E[m] is uniform across the wave.  M = 2^c <= 64 (one wave sums T)
+__device__ __forceinline__ void k_colsum_q16(uint32_t zk_nblk, const int16_t* __restrict__ q, uint32_t n, const Fr* __restrict__ E, uint32_t M, uint32_t c, uint32_t W,
                                                      uint32_t total_out, Fr* __restrict__ out) {
+  __shared__ Acc9 Csh;
+  if (threadIdx.x < 64) {
+    Col8 t;
+    col8_zero(t);
+    if (threadIdx.x < M) col8_mac(t, E[threadIdx.x], 1u);
+    col8_wave_sum(t);
+    if (threadIdx.x == 0) Csh = q16_offset_const(col8_carry(t), c);
+  }
+  __syncthreads();
+  const Acc9 C = Csh;
   for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total_out; idx += zk_nblk * blockDim.x) {
-    uint32_t h = idx / W, w = idx - h * W;
-    Acc9 acc = acc9_zero();
-    uint64_t base = (uint64_t)h * M * W + w;
+    const uint32_t h = idx / W, w = idx - h * W;
+    Col8 acc;
+    col8_zero(acc);
+    const uint64_t base = (uint64_t)h * M * W + w;
     for (uint32_t m = 0; m < M; m++) {
-      uint64_t src = base + (uint64_t)m * W;
-      if (src < n) acc9_mac(acc, E[m], q[src]);
+      const uint64_t src = base + (uint64_t)m * W;
+      const uint32_t u = src < n ? (uint32_t)((int32_t)q[src] + 32768) : 32768u;   // a missing element is the weight 0
+      col8_mac(acc, E[m], u);
     }
-    out[idx] = acc9_reduce(acc);
+    out[idx] = acc9_reduce(acc9_add(col8_carry(acc), C));
   }
 }
-// W == 1: one wave per output h, lanes stride the contiguous row
-__device__ __forceinline__ void k_dot_q16(uint32_t zk_nblk, const int16_t* __restrict__ q, uint32_t n, const Fr* __restrict__ E, uint32_t M, Fr* __restrict__ out,
+// W == 1: out[h] = sum_{m<M} E[m] q[h*M + m], M = 2^c a multiple of 128.  One wave per DOT_ROWS consecutive rows.
+static constexpr uint32_t DOT_ROWS = 4;
+__device__ __forceinline__ void k_dot_q16(uint32_t zk_nblk, const int16_t* __restrict__ q, uint32_t n, const Fr* __restrict__ E, uint32_t M, uint32_t c, Fr* __restrict__ out,
                                                   uint32_t H) {
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t h = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (h >= H) return;
-  uint64_t base = (uint64_t)h * M;
-  Acc9 acc = acc9_zero();
-  for (uint32_t m = lane; m < M; m += 64) {
-    uint64_t src = base + m;
-    if (src < n) acc9_mac(acc, E[m], q[src]);
-  }
-  acc = wave_sum_acc9(acc);
-  if (lane == 0) out[h] = acc9_reduce(acc);
-}
-// w (Montgomery) -> int16 if |w| < 2^15, else *overflow is set
-__device__ __forceinline__ void k_quant16(uint32_t zk_nblk, const Fr* __restrict__ t, uint32_t n, int16_t* __restrict__ q, uint32_t* __restrict__ overflow) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += zk_nblk * blockDim.x) {
-    Fr v = fr_unmont(t[i]);
-    Fr nv = fr_neg(v);
-    uint32_t hi_v = 0, hi_n = 0;
+  const uint32_t h0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * DOT_ROWS;
+  if (h0 >= H) return;
+  Col8 acc[DOT_ROWS], tsum;
 #pragma unroll
-    for (int l = 1; l < 8; l++) {
-      hi_v |= v.v[l];
-      hi_n |= nv.v[l];
+  for (uint32_t r = 0; r < DOT_ROWS; r++) col8_zero(acc[r]);
+  col8_zero(tsum);
+  for (uint32_t m = 2 * lane; m < M; m += 128) {
+    const Fr e0 = E[m], e1 = E[m + 1];
+    col8_mac(tsum, e0, 1u);
+    col8_mac(tsum, e1, 1u);
+#pragma unroll
+    for (uint32_t r = 0; r < DOT_ROWS; r++) {
+      const uint64_t src = (uint64_t)(h0 + r) * M + m;   // even: the two int16 are one aligned dword
+      uint32_t pair = 0x80008000u ^ 0x80008000u;          // two zero weights
+      if (h0 + r < H) {
+        if (src + 1 < n) pair = *reinterpret_cast<const uint32_t*>(q + src);
+        else if (src < n) pair = (uint32_t)(uint16_t)q[src];
+      }
+      const uint32_t u0 = ((pair & 0xffffu) ^ 0x8000u), u1 = ((pair >> 16) ^ 0x8000u);   // w + 2^15 for a two's complement int16
+      col8_mac(acc[r], e0, u0);
+      col8_mac(acc[r], e1, u1);
     }
-    int32_t r = 0;
-    if (hi_v == 0 && v.v[0] < 32768u) r = (int32_t)v.v[0];
-    else if (hi_n == 0 && nv.v[0] <= 32768u) r = -(int32_t)nv.v[0];
-    else atomicOr(overflow, 1u);
-    q[i] = (int16_t)r;
   }
-}
-int fr_quant16_dev(zk_ctx* ctx, const Fr* t, uint32_t n, int16_t* q, uint32_t* overflow_d) {
-  ZK_LAUNCHB(ctx, "fr_quant16", 34ull * n, 256, k_quant16, dim3(stream_grid(n)), 0, t, n, q, overflow_d);
-  return ZK_OK;
+  col8_wave_sum(tsum);
+  const Acc9 C = q16_offset_const(col8_carry(tsum), c);
+#pragma unroll
+  for (uint32_t r = 0; r < DOT_ROWS; r++) {
+    col8_wave_sum(acc[r]);
+    if (lane == r && h0 + r < H) out[h0 + r] = acc9_reduce(acc9_add(col8_carry(acc[r]), C));
+  }
 }
 
 // FrTensor::partial_me over the int16 copy of a quantised tensor: the first level (all the traffic) reads the
@@ -309,11 +362,11 @@ int fr_partial_me_q16_dev(zk_ctx* ctx, const int16_t* q, uint32_t n, const Fr* u
   ZK_ALLOC(ctx, E, Fr, M);
   ZK_TRY(eq_table(ctx, u_d, c, E.get()));
   const uint64_t bytes = 2ull * n + 32ull * ((uint64_t)H * W + M);
-  if (W == 1 && M >= 64) {
-    ZK_LAUNCHB(ctx, "fr_contract_q16", bytes, 256, k_dot_q16, dim3((H + 3) / 4), 0, q, n, (const Fr*)E.get(), M, out, H);
+  if (W == 1 && M >= 128) {
+    ZK_LAUNCHB(ctx, "fr_contract_q16", bytes, 256, k_dot_q16, dim3((H + 4 * DOT_ROWS - 1) / (4 * DOT_ROWS)), 0, q, n, (const Fr*)E.get(), M, c, out, H);
   } else {
     uint32_t total = H * W;
-    ZK_LAUNCHB(ctx, "fr_contract_q16", bytes, 256, k_colsum_q16, dim3(stream_grid(total)), 0, q, n, (const Fr*)E.get(), M, W, total, out);
+    ZK_LAUNCHB(ctx, "fr_contract_q16", bytes, 256, k_colsum_q16, dim3(stream_grid(total)), 0, q, n, (const Fr*)E.get(), M, c, W, total, out);
   }
   if (k == c) return ZK_OK;
   return fr_partial_me_dev(ctx, out, H * W, u_d + c, k - c, W, out_d);

@@ -386,6 +386,11 @@ __global__ void __launch_bounds__(1024) k_msm_sort(const MsmJob* __restrict__ jo
 // Each lane adds MSM_CHUNK consecutive items of the bucket-sorted list.  A bucket wholly inside the
 // chunk is stored to buckets[]; a bucket that started earlier goes to head[chunk], one that continues
 // later to tail[chunk].  grid (chunk blocks, jobs).
+// Stitching inside the wave: with ~n / 2^(c-1) items per bucket and 16 per chunk almost every straddling bucket spans exactly two
+// NEIGHBOURING chunks, i.e. two neighbouring lanes.  When both are lanes of this wave the second lane leaves its head piece in LDS and the
+// first adds it to its own last run and stores the complete bucket -- one more addition per wave (+9 % on sixteen mixed additions) instead
+// of a pass over every bucket of every MSM with two to four lanes each (k_msm_combine: 0.42 of this kernel's time on 4096-generator
+// layers, 0.12 of the issue peak); k_msm_combine keeps the buckets that cross a wave boundary or span three chunks or more.
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZK_ACCUM_WAVES, ZK_ACCUM_WAVES))) k_msm_accum(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ off,
                                                    G1X* __restrict__ buckets, G1X* __restrict__ head, G1X* __restrict__ tail) {
   const uint32_t B = 1u << (c - 1);
@@ -411,10 +416,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZK_ACCU
   const uint32_t* items = idx + job.item_off;
   G1X acc = g1x_zero();
   G1X* bk = buckets + (uint64_t)q * B;
+  __shared__ G1X stitch[64];
+  // this lane's FIRST run is the second half of a bucket that began in the previous lane's chunk and ends in this one
+  const bool give = threadIdx.x > 0 && o[b] < cs && o[b] + MSM_CHUNK >= cs && bend <= ce;
   for (uint32_t p = cs; p < ce; p++) {
     while (p >= bend) {  // bucket b ends here (possibly followed by empty buckets)
       if (p > run_start) {
         if (run_start == o[b]) bk[b - 1] = acc;                     // complete: started and ended inside this chunk
+        else if (give) stitch[threadIdx.x] = acc;                    // started in the previous lane's chunk: that lane completes it
         else head[job.chunk_off + t] = acc;                          // started in an earlier chunk
         acc = g1x_zero();
       }
@@ -438,9 +447,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZK_ACCU
   }
   // last run of the chunk: [run_start, ce) of bucket b
   bool starts = run_start == o[b], ends = ce == bend;
+  // this lane's LAST run is the first half of a bucket that ends in the next lane's chunk (the mirror image of `give` there)
+  const bool take = !ends && threadIdx.x < 63u && o[b] >= cs && (uint64_t)bend <= (uint64_t)cs + 2u * MSM_CHUNK;
   if (starts && ends) bk[b - 1] = acc;
-  else if (run_start == cs) head[job.chunk_off + t] = acc;  // reaches back to the chunk start (spans the whole chunk or came from before)
-  else tail[job.chunk_off + t] = acc;                        // starts inside, continues into the next chunk
+  else if (take) {}                                           // completed below
+  else if (run_start == cs) {                                 // reaches back to the chunk start (spans the whole chunk or came from before)
+    if (give && ends) stitch[threadIdx.x] = acc;
+    else head[job.chunk_off + t] = acc;
+  } else tail[job.chunk_off + t] = acc;                       // starts inside, continues into the next chunk
+  __syncthreads();                                            // (one wave per workgroup: lanes that left early do not take part)
+  if (take) bk[b - 1] = g1x_add(acc, stitch[threadIdx.x + 1]);
 }
 
 // LPB lanes per (job, bucket): empty -> infinity; split across chunks -> sum of the chunk partials, each lane
@@ -463,7 +479,8 @@ __global__ void __launch_bounds__(64) k_msm_combine(const MsmJob* __restrict__ j
   bool store = live && s == e;  // empty bucket: infinity
   if (live && s != e) {
     const uint32_t t0 = (s - base) / MSM_CHUNK, t1 = (e - 1 - base) / MSM_CHUNK;
-    if (t0 != t1) {  // (t0 == t1: complete inside one chunk, already stored by k_msm_accum)
+    // (t0 == t1: complete inside one chunk; two neighbouring chunks of one wave: stitched there -- both already stored by k_msm_accum)
+    if (t0 != t1 && !(t1 == t0 + 1 && (t0 & 63u) != 63u)) {
       store = true;
       // chunk t0 holds the bucket's first piece: a tail unless the bucket starts exactly at the chunk start
       if (sub == 0) acc = ((s - base) == t0 * MSM_CHUNK) ? head[job.chunk_off + t0] : tail[job.chunk_off + t0];
