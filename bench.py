@@ -892,7 +892,7 @@ def main():
         W_ft = (254 + 2 + wl.full_tables - 1) // wl.full_tables
         ft_pairs = real_pairs - sum(s_["m"] for s_ in wl.shapes)
         macs_per_step["msm_table_accum"] = ft_pairs * W_ft * 10 * FP_MACS
-        macs_per_step["msm_table_sum"] = ft_pairs * W_ft / 16.0 * 14 * FP_MACS
+        macs_per_step["msm_table_sum"] = ft_pairs * W_ft / 32.0 * 14 * FP_MACS      # one partial per 2 x 16 items (msm.hip: MSM_CHUNK x FT_SUBS)
         fam["msm_table_accum"] = (["k_msmf_accum"], 100, None)
         fam["msm_table_sum"] = (["k_msmf_reduce"], None, None)
     if args.msm == "pippenger":

@@ -343,6 +343,29 @@ __device__ __forceinline__ void k_dot_q16(uint32_t zk_nblk, const int16_t* __res
   }
 }
 
+// w (Montgomery) -> int16 if |w| < 2^15, else *overflow is set
+__device__ __forceinline__ void k_quant16(uint32_t zk_nblk, const Fr* __restrict__ t, uint32_t n, int16_t* __restrict__ q, uint32_t* __restrict__ overflow) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += zk_nblk * blockDim.x) {
+    Fr v = fr_unmont(t[i]);
+    Fr nv = fr_neg(v);
+    uint32_t hi_v = 0, hi_n = 0;
+#pragma unroll
+    for (int l = 1; l < 8; l++) {
+      hi_v |= v.v[l];
+      hi_n |= nv.v[l];
+    }
+    int32_t r = 0;
+    if (hi_v == 0 && v.v[0] < 32768u) r = (int32_t)v.v[0];
+    else if (hi_n == 0 && nv.v[0] <= 32768u) r = -(int32_t)nv.v[0];
+    else atomicOr(overflow, 1u);
+    q[i] = (int16_t)r;
+  }
+}
+int fr_quant16_dev(zk_ctx* ctx, const Fr* t, uint32_t n, int16_t* q, uint32_t* overflow_d) {
+  ZK_LAUNCHB(ctx, "fr_quant16", 34ull * n, 256, k_quant16, dim3(stream_grid(n)), 0, t, n, q, overflow_d);
+  return ZK_OK;
+}
+
 // FrTensor::partial_me over the int16 copy of a quantised tensor: the first level (all the traffic) reads the
 // int16s, the remaining levels fold its Fr output exactly as fr_partial_me_dev does
 int fr_partial_me_q16_dev(zk_ctx* ctx, const int16_t* q, uint32_t n, const Fr* u_d, uint32_t k, uint32_t W, Fr* out_d) {

@@ -637,6 +637,10 @@ struct FullJob {
   uint64_t part_off;
 };
 static constexpr uint32_t FT_SEG = 64;  // points put into affine form per shared inversion
+#ifndef ZK_FT_SUBS
+#define ZK_FT_SUBS 2
+#endif
+static constexpr uint32_t FT_SUBS = ZK_FT_SUBS;  // chunks of MSM_CHUNK items a lane of k_msmf_accum adds into its one partial
 __global__ void __launch_bounds__(64) k_fulltable_build(const G1A* __restrict__ win, const uint8_t* __restrict__ inf, uint32_t n, uint32_t W, uint32_t half,
                                                          G1AE* __restrict__ out, G1X* __restrict__ scratch, Fq* __restrict__ prefix) {
   const uint32_t row = blockIdx.x * 64u + threadIdx.x;  // row = j * W + w
@@ -696,14 +700,20 @@ __device__ __forceinline__ void msmf_accum_body(const FullJob* __restrict__ jobs
   const FullJob job = jobs[blockIdx.y];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t items = (uint64_t)job.nnz * job.W;
-  const uint64_t e0 = (uint64_t)t * MSM_CHUNK;
-  if (e0 >= items) return;
-  const uint64_t e1 = e0 + MSM_CHUNK < items ? e0 + MSM_CHUNK : items;
-  const uint32_t pt0 = (uint32_t)(e0 / job.W), w0 = (uint32_t)(e0 - (uint64_t)pt0 * job.W);
+  if ((uint64_t)t * (MSM_CHUNK * FT_SUBS) >= items) return;
   const uint32_t half_log = c - 1;
   const ZK_GLOBAL G1AE* tab = (const ZK_GLOBAL G1AE*)job.tab;
   const ZK_GLOBAL Fr* mags = (const ZK_GLOBAL Fr*)job.mags;
   const ZK_GLOBAL uint8_t* inf = (const ZK_GLOBAL uint8_t*)job.inf;
+  G1X acc = g1x_zero();
+  // FT_SUBS consecutive chunks of MSM_CHUNK items go into ONE partial: half as many partials for k_msmf_reduce to add (its 14-product additions were
+  // 9 % of this kernel's 10-product ones), the same offsets-then-additions structure per chunk
+#pragma unroll 1
+  for (uint32_t sub = 0; sub < FT_SUBS; sub++) {
+  const uint64_t e0 = ((uint64_t)t * FT_SUBS + sub) * MSM_CHUNK;
+  if (e0 >= items) break;
+  const uint64_t e1 = e0 + MSM_CHUNK < items ? e0 + MSM_CHUNK : items;
+  const uint32_t pt0 = (uint32_t)(e0 / job.W), w0 = (uint32_t)(e0 - (uint64_t)pt0 * job.W);
   // pass 1 (integer work only): the chunk's table offsets; bit 63 = negate, ~0 = nothing to add (digit 0, infinite base).  A chunk of 16
   // point-major items touches at most two points when a point has >= 16 windows (every width up to 16 bits): both scalars are requested at
   // once -- one wait instead of a dependent load + wait per item
@@ -781,7 +791,6 @@ __device__ __forceinline__ void msmf_accum_body(const FullJob* __restrict__ jobs
     }
     return r;
   };
-  G1X acc = g1x_zero();
   G1A q[AHEAD];
 #pragma unroll
   for (int a = 0; a < AHEAD; a++)
@@ -796,6 +805,7 @@ __device__ __forceinline__ void msmf_accum_body(const FullJob* __restrict__ jobs
       acc = g1x_madd<INL>(acc, fq_unpack(P.x), fq_unpack(P.y));
     }
   }
+  }  // sub
   partial[job.part_off + t] = acc;
 }
 // variants (ZKDL_FT_VARIANT, experiments): 0 = inlined products, 2 waves/SIMD, 1 entry ahead (default); 1 = two entries ahead; 2 = products as calls, 3 waves;
@@ -818,7 +828,7 @@ __global__ void __launch_bounds__(256) k_msmf_reduce(const FullJob* __restrict__
   __shared__ G1X sm[4];
   const FullJob job = jobs[blockIdx.x];
   const uint64_t items = (uint64_t)job.nnz * job.W;
-  const uint32_t np = (uint32_t)((items + MSM_CHUNK - 1) / MSM_CHUNK);
+  const uint32_t np = (uint32_t)((items + MSM_CHUNK * FT_SUBS - 1) / (MSM_CHUNK * FT_SUBS));
   G1X acc = g1x_zero();
   for (uint32_t p = threadIdx.x; p < np; p += 256) acc = g1x_add(acc, partial[job.part_off + p]);
 #pragma unroll 1
@@ -883,7 +893,7 @@ static int msm_run_full_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs) 
     j.nnz = h.pat_r == 0xff ? j.n : j.n / 2;
     j.part_off = parts;
     const uint64_t items = (uint64_t)j.nnz * W;
-    const uint32_t lanes = (uint32_t)((items + MSM_CHUNK - 1) / MSM_CHUNK);
+    const uint32_t lanes = (uint32_t)((items + MSM_CHUNK * FT_SUBS - 1) / (MSM_CHUNK * FT_SUBS));
     parts += lanes;
     items_all += items;
     max_lanes = lanes > max_lanes ? lanes : max_lanes;
