@@ -280,19 +280,19 @@ __device__ __forceinline__ Acc9 q16_offset_const(const Acc9& T, uint32_t c) {
   for (int i = 0; i < 9; i++) r.v[i] = (d.v[i] << 15) | (i ? d.v[i - 1] >> 17 : 0u);
   return r;
 }
-// out[h*W + w] = sum_{m<M} E[m] * q[(h*M + m)*W + w]; one thread per output; E[m] is uniform across the wave.  M = 2^c <= 64 (one wave sums T)
-__device__ __forceinline__ void k_colsum_q16(uint32_t zk_nblk, const int16_t* __restrict__ q, uint32_t n, const Fr* __restrict__ E, uint32_t M, uint32_t c, uint32_t W,
+// the offset constant of one launch shape (one wave): C = 2^15 (M r - sum_m E[m])
+__device__ __forceinline__ void k_q16_offset(uint32_t zk_nblk, const Fr* __restrict__ E, uint32_t M, uint32_t c, Acc9* __restrict__ out) {
+  if (blockIdx.x) return;
+  Col8 t;
+  col8_zero(t);
+  for (uint32_t m = threadIdx.x; m < M; m += 64) col8_mac(t, E[m], 1u);
+  col8_wave_sum(t);
+  if (threadIdx.x == 0) *out = q16_offset_const(col8_carry(t), c);
+}
+// out[h*W + w] = sum_{m<M} E[m] * q[(h*M + m)*W + w]; one thread per output; E[m] is uniform across the wave
+__device__ __forceinline__ void k_colsum_q16(uint32_t zk_nblk, const int16_t* __restrict__ q, uint32_t n, const Fr* __restrict__ E, uint32_t M, const Acc9* __restrict__ Cp, uint32_t W,
                                                      uint32_t total_out, Fr* __restrict__ out) {
-  __shared__ Acc9 Csh;
-  if (threadIdx.x < 64) {
-    Col8 t;
-    col8_zero(t);
-    if (threadIdx.x < M) col8_mac(t, E[threadIdx.x], 1u);
-    col8_wave_sum(t);
-    if (threadIdx.x == 0) Csh = q16_offset_const(col8_carry(t), c);
-  }
-  __syncthreads();
-  const Acc9 C = Csh;
+  const Acc9 C = *Cp;
   for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total_out; idx += zk_nblk * blockDim.x) {
     const uint32_t h = idx / W, w = idx - h * W;
     Col8 acc;
@@ -306,25 +306,23 @@ __device__ __forceinline__ void k_colsum_q16(uint32_t zk_nblk, const int16_t* __
     out[idx] = acc9_reduce(acc9_add(col8_carry(acc), C));
   }
 }
-// W == 1: out[h] = sum_{m<M} E[m] q[h*M + m], M = 2^c a multiple of 128.  One wave per DOT_ROWS consecutive rows.
-static constexpr uint32_t DOT_ROWS = 4;
-__device__ __forceinline__ void k_dot_q16(uint32_t zk_nblk, const int16_t* __restrict__ q, uint32_t n, const Fr* __restrict__ E, uint32_t M, uint32_t c, Fr* __restrict__ out,
-                                                  uint32_t H) {
+// W == 1: out[h] = sum_{m<M} E[m] q[h*M + m], M = 2^c a multiple of 128.  One wave per DOT_ROWS consecutive rows: a lane's two table entries of a
+// step (64 bytes from L1) serve 2 x DOT_ROWS weights -- at four rows the kernel ran at the L1 read bandwidth, not at the MAC rate
+static constexpr uint32_t DOT_ROWS = 8;
+__device__ __forceinline__ void k_dot_q16(uint32_t zk_nblk, const int16_t* __restrict__ q, uint32_t n, const Fr* __restrict__ E, uint32_t M, const Acc9* __restrict__ Cp,
+                                                  Fr* __restrict__ out, uint32_t H) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t h0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * DOT_ROWS;
   if (h0 >= H) return;
-  Col8 acc[DOT_ROWS], tsum;
+  Col8 acc[DOT_ROWS];
 #pragma unroll
   for (uint32_t r = 0; r < DOT_ROWS; r++) col8_zero(acc[r]);
-  col8_zero(tsum);
   for (uint32_t m = 2 * lane; m < M; m += 128) {
     const Fr e0 = E[m], e1 = E[m + 1];
-    col8_mac(tsum, e0, 1u);
-    col8_mac(tsum, e1, 1u);
 #pragma unroll
     for (uint32_t r = 0; r < DOT_ROWS; r++) {
       const uint64_t src = (uint64_t)(h0 + r) * M + m;   // even: the two int16 are one aligned dword
-      uint32_t pair = 0x80008000u ^ 0x80008000u;          // two zero weights
+      uint32_t pair = 0u;                                 // two zero weights
       if (h0 + r < H) {
         if (src + 1 < n) pair = *reinterpret_cast<const uint32_t*>(q + src);
         else if (src < n) pair = (uint32_t)(uint16_t)q[src];
@@ -334,8 +332,7 @@ __device__ __forceinline__ void k_dot_q16(uint32_t zk_nblk, const int16_t* __res
       col8_mac(acc[r], e1, u1);
     }
   }
-  col8_wave_sum(tsum);
-  const Acc9 C = q16_offset_const(col8_carry(tsum), c);
+  const Acc9 C = *Cp;
 #pragma unroll
   for (uint32_t r = 0; r < DOT_ROWS; r++) {
     col8_wave_sum(acc[r]);
@@ -384,12 +381,14 @@ int fr_partial_me_q16_dev(zk_ctx* ctx, const int16_t* q, uint32_t n, const Fr* u
   }
   ZK_ALLOC(ctx, E, Fr, M);
   ZK_TRY(eq_table(ctx, u_d, c, E.get()));
+  ZK_ALLOC(ctx, C, Acc9, 1);
+  ZK_LAUNCHB(ctx, "eq_table", 32ull * M, 64, k_q16_offset, dim3(1), 0, (const Fr*)E.get(), M, c, C.get());
   const uint64_t bytes = 2ull * n + 32ull * ((uint64_t)H * W + M);
   if (W == 1 && M >= 128) {
-    ZK_LAUNCHB(ctx, "fr_contract_q16", bytes, 256, k_dot_q16, dim3((H + 4 * DOT_ROWS - 1) / (4 * DOT_ROWS)), 0, q, n, (const Fr*)E.get(), M, c, out, H);
+    ZK_LAUNCHB(ctx, "fr_contract_q16", bytes, 256, k_dot_q16, dim3((H + 4 * DOT_ROWS - 1) / (4 * DOT_ROWS)), 0, q, n, (const Fr*)E.get(), M, (const Acc9*)C.get(), out, H);
   } else {
     uint32_t total = H * W;
-    ZK_LAUNCHB(ctx, "fr_contract_q16", bytes, 256, k_colsum_q16, dim3(stream_grid(total)), 0, q, n, (const Fr*)E.get(), M, c, W, total, out);
+    ZK_LAUNCHB(ctx, "fr_contract_q16", bytes, 256, k_colsum_q16, dim3(stream_grid(total)), 0, q, n, (const Fr*)E.get(), M, (const Acc9*)C.get(), W, total, out);
   }
   if (k == c) return ZK_OK;
   return fr_partial_me_dev(ctx, out, H * W, u_d + c, k - c, W, out_d);

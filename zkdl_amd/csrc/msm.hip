@@ -477,18 +477,24 @@ __global__ void __launch_bounds__(64) k_msm_combine(const MsmJob* __restrict__ j
   const uint32_t s = live ? o[b] : 0, e = live ? o[b + 1] : 0;
   G1X acc = g1x_zero();
   bool store = live && s == e;  // empty bucket: infinity
+  bool pieces = false;          // this bucket's chunk partials are added here (then the butterfly below has something to join)
   if (live && s != e) {
     const uint32_t t0 = (s - base) / MSM_CHUNK, t1 = (e - 1 - base) / MSM_CHUNK;
     // (t0 == t1: complete inside one chunk; two neighbouring chunks of one wave: stitched there -- both already stored by k_msm_accum)
     if (t0 != t1 && !(t1 == t0 + 1 && (t0 & 63u) != 63u)) {
       store = true;
+      pieces = true;
       // chunk t0 holds the bucket's first piece: a tail unless the bucket starts exactly at the chunk start
       if (sub == 0) acc = ((s - base) == t0 * MSM_CHUNK) ? head[job.chunk_off + t0] : tail[job.chunk_off + t0];
       for (uint32_t t = t0 + 1 + sub; t <= t1; t += LPB) acc = g1x_add(acc, head[job.chunk_off + t]);
     }
   }
+  // with the stitching inside k_msm_accum most waves have no bucket left to join: the butterfly (LPB / 2 .. LPB full additions per lane, whatever the
+  // operands) is skipped wave by wave
+  if (__builtin_amdgcn_ballot_w64(pieces) != 0ull) {
 #pragma unroll
-  for (int m = 1; m < LPB; m <<= 1) acc = g1x_add(acc, g1x_shfl_xor(acc, m));
+    for (int m = 1; m < LPB; m <<= 1) acc = g1x_add(acc, g1x_shfl_xor(acc, m));
+  }
   if (store && sub == 0) buckets[(uint64_t)q * B + (b - 1)] = acc;
 }
 
