@@ -520,6 +520,9 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="finish every proof on the main stream (no overlap of proof i's G1 phase with proof i+1's Fr phase)")
     ap.add_argument("--backend", default=os.environ.get("BENCH_BACKEND", "nccl"), help="nccl (= RCCL, default) | gloo (rehearsal on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses device 0")
+    ap.add_argument("--spawn", action="store_true", help="start the rank(s) as child processes even for --gpus 1 (the launcher path a multi-GPU run takes)")
+    ap.add_argument("--collective", action="store_true", help="create the process group and run the aggregate's all-reduce even with one rank "
+                    "(with --backend nccl: RCCL initialised and used on the single GPU a test box has)")
     ap.add_argument("--mode", default="independent", choices=["independent", "shard"],
                     help="independent (default, the bench contract): every rank proves its own batches, one all-reduce of the run aggregate; "
                          "shard: the N ranks prove ONE batch together, sharded by batch rows (zkdl_amd/shard.py: strong scaling of a single proof, "
@@ -565,7 +568,7 @@ def main():
                 h.wait(timeout=300)
             except subprocess.TimeoutExpired:
                 h.kill()
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
@@ -592,7 +595,8 @@ def main():
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    coll = world > 1 or args.collective           # a process group exists (N > 1, or one rank with --collective)
+    if coll:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -653,7 +657,7 @@ def main():
     def barrier():
         zk.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if coll:
             dist.barrier()
 
     t_spin = time.perf_counter()
@@ -680,7 +684,7 @@ def main():
     # warm what closes the timed region as well: the row sum is a torch kernel whose first launch in a process loads its code object
     # (~7 ms measured: 0.35 ms per step of a 20-step run; tools/notorch_bench.py runs the same loop without torch: 3.52 ms per proof at K = 20 and K = 100)
     warm_agg = rows[:args.steps].sum(dim=0)
-    if world > 1:                                # ... and the communicator
+    if coll:                                # ... and the communicator
         dist.all_reduce(warm_agg, op=dist.ReduceOp.SUM)
     barrier()
     # keep the collector out of the timed region: a generation-2 pass over torch's object graph costs ~40 ms,
@@ -711,7 +715,7 @@ def main():
     t_enq = time.perf_counter() - t0          # host time to enqueue K steps (no device wait inside)
     zk.sync()                                 # all G1 streams joined: every row is final
     agg = rows[:args.steps].sum(dim=0)        # < K * 2^32 per lane: exact in int64
-    if world > 1:
+    if coll:
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)      # RCCL over xGMI: 8 x uint64 lanes, once per run
     barrier()
     elapsed = time.perf_counter() - t0
@@ -719,7 +723,7 @@ def main():
     zk.set_flag("derive_rounds", 1 if derive else 0)
     zk.set_flag("g1_batch", max(1, args.g1_batch))
     per_rank_ms = [elapsed * 1e3 / max(args.steps, 1)]
-    if world > 1:
+    if coll:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
@@ -728,7 +732,7 @@ def main():
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
     value = ms_per_step / (batch * world)
     rank_devices = [local_rank]
-    if world > 1:                                        # which device every rank proved on, as the ranks themselves report it
+    if coll:                                        # which device every rank proved on, as the ranks themselves report it
         dv = torch.tensor([torch.cuda.current_device()], dtype=torch.int64, device="cuda")
         alld = [torch.zeros_like(dv) for _ in range(world)]
         dist.all_gather(alld, dv)
@@ -892,7 +896,7 @@ def main():
         W_ft = (254 + 2 + wl.full_tables - 1) // wl.full_tables
         ft_pairs = real_pairs - sum(s_["m"] for s_ in wl.shapes)
         macs_per_step["msm_table_accum"] = ft_pairs * W_ft * 10 * FP_MACS
-        macs_per_step["msm_table_sum"] = ft_pairs * W_ft / 32.0 * 14 * FP_MACS      # one partial per 2 x 16 items (msm.hip: MSM_CHUNK x FT_SUBS)
+        macs_per_step["msm_table_sum"] = ft_pairs * W_ft / 16.0 * 14 * FP_MACS      # one partial per 16 items (msm.hip: MSM_CHUNK x FT_SUBS)
         fam["msm_table_accum"] = (["k_msmf_accum"], 100, None)
         fam["msm_table_sum"] = (["k_msmf_reduce"], None, None)
     if args.msm == "pippenger":
@@ -1014,8 +1018,8 @@ def main():
                       "schedule_note": "the last drain_form_proofs proofs of the timed region run every round commitment as an MSM (derive_rounds off) and their G1 phases unbatched (g1_batch 1): they have no later proof to hide a long G1 chain under"},
            "ms_per_proof": ms_per_step, "steady_state_ms_per_proof": (steady["ms_per_proof"] if steady else None), "steady_state": steady,
            "latency_ms_per_proof": (min(v["median_ms"] for v in latency.values() if isinstance(v, dict)) if latency else None), "latency": latency, "extensions": extensions,
-           "per_rank_ms_per_proof": per_rank_ms, "collective_world_size": (dist.get_world_size() if world > 1 else 1),
-           "collective_backend": (dist.get_backend() if world > 1 else None), "rank_devices": rank_devices,
+           "per_rank_ms_per_proof": per_rank_ms, "collective_world_size": (dist.get_world_size() if coll else 1),
+           "collective_backend": (dist.get_backend() if coll else None), "rank_devices": rank_devices,
            "host_enqueue_ms_per_step": t_enq * 1e3 / max(args.steps, 1), "aggregate_fr": hex(aggregate), "setup": wl.info, "roofline": roofline,
            "roofline_chip_filling": roofline_fill, "roofline_all": roofline_all, "g1_model": g1_model, "kernels": kernels,
            "g1_msm_mops_commit": wl.info["commit_mops"]}
@@ -1026,11 +1030,11 @@ def main():
         # BASELINE's second metric, "G1 MSM Mop/s at 1/2/4/8 GPUs": every rank runs the same 2^24-pair probe on its own device at the same time
         # (independent MSMs over replicated generators: the rows-of-W partitioning of SURVEY 8e, no exchange); the job figure is all ranks' pairs
         # over the slowest rank's time
-        if world > 1:
+        if coll:
             dist.barrier()
         mine = msm_fullwidth_probe(zk, full_tables=wl.full_tables)
         out["g1_msm_fullwidth"] = mine
-        if world > 1:
+        if coll:
             t = torch.tensor([mine["ms"]], dtype=torch.float64, device="cuda")
             allt = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(allt, t)
@@ -1041,7 +1045,7 @@ def main():
             out["g1_msm_mops"] = mine["mops"]
         if wl.full_tables and rank == 0 and world == 1:
             out["g1_msm_fullwidth_bucket_method"] = msm_fullwidth_probe(zk, full_tables=0)
-    if world > 1:
+    if coll:
         dist.barrier()
     rc = 0
     if want_cpu:
@@ -1053,7 +1057,7 @@ def main():
                 rc = 4
     if rank == 0:
         emit(out, args.detail_out)
-    if world > 1:
+    if coll:
         dist.destroy_process_group()
     zk.close()
     if rc:

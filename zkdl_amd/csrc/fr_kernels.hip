@@ -293,6 +293,10 @@ __device__ __forceinline__ void k_q16_offset(uint32_t zk_nblk, const Fr* __restr
 __device__ __forceinline__ void k_colsum_q16(uint32_t zk_nblk, const int16_t* __restrict__ q, uint32_t n, const Fr* __restrict__ E, uint32_t M, const Acc9* __restrict__ Cp, uint32_t W,
                                                      uint32_t total_out, Fr* __restrict__ out) {
   const Acc9 C = *Cp;
+  // E[m] is the same for every lane: read it through the constant address space, i.e. as SCALAR loads (the table was written by an earlier launch) --
+  // as 32 bytes per lane and weight from L1 the loop ran at the L1 read bandwidth (2 KB per wave and step), 3.5x below its MAC rate
+  const __attribute__((address_space(4))) uint32_t* Ec = (const __attribute__((address_space(4))) uint32_t*)E;
+  const __attribute__((address_space(1))) int16_t* qg = (const __attribute__((address_space(1))) int16_t*)q;
   for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total_out; idx += zk_nblk * blockDim.x) {
     const uint32_t h = idx / W, w = idx - h * W;
     Col8 acc;
@@ -300,8 +304,11 @@ __device__ __forceinline__ void k_colsum_q16(uint32_t zk_nblk, const int16_t* __
     const uint64_t base = (uint64_t)h * M * W + w;
     for (uint32_t m = 0; m < M; m++) {
       const uint64_t src = base + (uint64_t)m * W;
-      const uint32_t u = src < n ? (uint32_t)((int32_t)q[src] + 32768) : 32768u;   // a missing element is the weight 0
-      col8_mac(acc, E[m], u);
+      const uint32_t u = src < n ? (uint32_t)((int32_t)qg[src] + 32768) : 32768u;   // a missing element is the weight 0
+      Fr e;
+#pragma unroll
+      for (int l = 0; l < 8; l++) e.v[l] = Ec[8u * m + l];
+      col8_mac(acc, e, u);
     }
     out[idx] = acc9_reduce(acc9_add(col8_carry(acc), C));
   }

@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(1024) k_msm_sort(const MsmJob* __restrict__ jo
 // first adds it to its own last run and stores the complete bucket -- one more addition per wave (+9 % on sixteen mixed additions) instead
 // of a pass over every bucket of every MSM with two to four lanes each (k_msm_combine: 0.42 of this kernel's time on 4096-generator
 // layers, 0.12 of the issue peak); k_msm_combine keeps the buckets that cross a wave boundary or span three chunks or more.
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZK_ACCUM_WAVES, ZK_ACCUM_WAVES))) k_msm_accum(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ off,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZK_ACCUM_WAVES, ZK_ACCUM_WAVES))) k_msm_accum(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t chunk, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ off,
                                                    G1X* __restrict__ buckets, G1X* __restrict__ head, G1X* __restrict__ tail) {
   const uint32_t B = 1u << (c - 1);
   const uint32_t q = blockIdx.y;
@@ -399,10 +399,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZK_ACCU
   const uint32_t* o = off + (uint64_t)q * (B + 2);
   const uint32_t base = o[1], total = o[B + 1];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t cs64 = (uint64_t)base + (uint64_t)t * MSM_CHUNK;
+  const uint64_t cs64 = (uint64_t)base + (uint64_t)t * chunk;
   if (cs64 >= total) return;
   const uint32_t cs = (uint32_t)cs64;
-  const uint32_t ce = cs + MSM_CHUNK < total ? cs + MSM_CHUNK : total;
+  const uint32_t ce = cs + chunk < total ? cs + chunk : total;
   // bucket containing item cs: largest b in [1, B] with o[b] <= cs
   uint32_t lo = 1, hi = B;
   while (lo < hi) {
@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZK_ACCU
   G1X* bk = buckets + (uint64_t)q * B;
   __shared__ G1X stitch[64];
   // this lane's FIRST run is the second half of a bucket that began in the previous lane's chunk and ends in this one
-  const bool give = threadIdx.x > 0 && o[b] < cs && o[b] + MSM_CHUNK >= cs && bend <= ce;
+  const bool give = threadIdx.x > 0 && o[b] < cs && o[b] + chunk >= cs && bend <= ce;
   for (uint32_t p = cs; p < ce; p++) {
     while (p >= bend) {  // bucket b ends here (possibly followed by empty buckets)
       if (p > run_start) {
@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZK_ACCU
   // last run of the chunk: [run_start, ce) of bucket b
   bool starts = run_start == o[b], ends = ce == bend;
   // this lane's LAST run is the first half of a bucket that ends in the next lane's chunk (the mirror image of `give` there)
-  const bool take = !ends && threadIdx.x < 63u && o[b] >= cs && (uint64_t)bend <= (uint64_t)cs + 2u * MSM_CHUNK;
+  const bool take = !ends && threadIdx.x < 63u && o[b] >= cs && (uint64_t)bend <= (uint64_t)cs + 2ull * chunk;
   if (starts && ends) bk[b - 1] = acc;
   else if (take) {}                                           // completed below
   else if (run_start == cs) {                                 // reaches back to the chunk start (spans the whole chunk or came from before)
@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZK_ACCU
 // or two bits of entropy, so for some window widths half of all points of an MSM land in one bucket: a single
 // lane would walk ~100 additions there.)
 template <int LPB>  // lanes per bucket: 2 when buckets span few chunks, 4 when a near-empty top window makes hot buckets
-__global__ void __launch_bounds__(64) k_msm_combine(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ off, G1X* __restrict__ buckets,
+__global__ void __launch_bounds__(64) k_msm_combine(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t chunk, const uint32_t* __restrict__ off, G1X* __restrict__ buckets,
                                                      const G1X* __restrict__ head, const G1X* __restrict__ tail) {
   const uint32_t B = 1u << (c - 1);
   const uint32_t q = blockIdx.y;
@@ -479,13 +479,13 @@ __global__ void __launch_bounds__(64) k_msm_combine(const MsmJob* __restrict__ j
   bool store = live && s == e;  // empty bucket: infinity
   bool pieces = false;          // this bucket's chunk partials are added here (then the butterfly below has something to join)
   if (live && s != e) {
-    const uint32_t t0 = (s - base) / MSM_CHUNK, t1 = (e - 1 - base) / MSM_CHUNK;
+    const uint32_t t0 = (s - base) / chunk, t1 = (e - 1 - base) / chunk;
     // (t0 == t1: complete inside one chunk; two neighbouring chunks of one wave: stitched there -- both already stored by k_msm_accum)
     if (t0 != t1 && !(t1 == t0 + 1 && (t0 & 63u) != 63u)) {
       store = true;
       pieces = true;
       // chunk t0 holds the bucket's first piece: a tail unless the bucket starts exactly at the chunk start
-      if (sub == 0) acc = ((s - base) == t0 * MSM_CHUNK) ? head[job.chunk_off + t0] : tail[job.chunk_off + t0];
+      if (sub == 0) acc = ((s - base) == t0 * chunk) ? head[job.chunk_off + t0] : tail[job.chunk_off + t0];
       for (uint32_t t = t0 + 1 + sub; t <= t1; t += LPB) acc = g1x_add(acc, head[job.chunk_off + t]);
     }
   }
@@ -644,7 +644,7 @@ struct FullJob {
 };
 static constexpr uint32_t FT_SEG = 64;  // points put into affine form per shared inversion
 #ifndef ZK_FT_SUBS
-#define ZK_FT_SUBS 2
+#define ZK_FT_SUBS 1
 #endif
 static constexpr uint32_t FT_SUBS = ZK_FT_SUBS;  // chunks of MSM_CHUNK items a lane of k_msmf_accum adds into its one partial
 __global__ void __launch_bounds__(64) k_fulltable_build(const G1A* __restrict__ win, const uint8_t* __restrict__ inf, uint32_t n, uint32_t W, uint32_t half,
@@ -712,8 +712,8 @@ __device__ __forceinline__ void msmf_accum_body(const FullJob* __restrict__ jobs
   const ZK_GLOBAL Fr* mags = (const ZK_GLOBAL Fr*)job.mags;
   const ZK_GLOBAL uint8_t* inf = (const ZK_GLOBAL uint8_t*)job.inf;
   G1X acc = g1x_zero();
-  // FT_SUBS consecutive chunks of MSM_CHUNK items go into ONE partial: half as many partials for k_msmf_reduce to add (its 14-product additions were
-  // 9 % of this kernel's 10-product ones), the same offsets-then-additions structure per chunk
+  // FT_SUBS consecutive chunks of MSM_CHUNK items go into ONE partial.  Measured at 2 (round 4): k_msmf_reduce 0.36 -> 0.27 ms per proof (half the partials), this
+  // kernel 0.78 -> 0.95 (half the lanes: the last round of waves is half empty on the G1 stream's half of the chip); kept at 1
 #pragma unroll 1
   for (uint32_t sub = 0; sub < FT_SUBS; sub++) {
   const uint64_t e0 = ((uint64_t)t * FT_SUBS + sub) * MSM_CHUNK;
@@ -944,6 +944,13 @@ static int msm_run_bucket_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs
   std::vector<MsmJob> jobs(nj);
   uint64_t items = 0, chunks = 0, pairs = 0;
   uint32_t max_chunks = 0, Wmax = 0;
+  // items per lane: MSM_CHUNK (16: the critical path of a proof-sized batch), doubled while the batch still fills the chip several times over.  A bucket
+  // holds n W / 2^(c-1) items (all windows share the buckets: the tables carry 2^(c w)), 104-208 on 2048-4096-generator layers: at 16 per chunk a bucket is
+  // 7-13 pieces for k_msm_combine to add (0.42 of the accumulation's time on the depth-64 model), at 64 two to four, half of which the wave stitches itself
+  uint64_t all_items = 0;
+  for (uint32_t i = 0; i < nj; i++) all_items += (uint64_t)hjobs[i].T->n * hjobs[i].W;
+  uint32_t chunk = MSM_CHUNK;
+  while (chunk < 64u && all_items / (2ull * chunk) >= (1ull << 20)) chunk *= 2;
   for (uint32_t i = 0; i < nj; i++) {
     const MsmJobHost& h = hjobs[i];
     if (h.W > h.T->W || h.T->c != c) return ctx->fail(ZK_ERR_ARG, "MSM: job/table window mismatch");
@@ -957,7 +964,7 @@ static int msm_run_bucket_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs
     j.item_off = items;
     j.chunk_off = chunks;
     uint64_t ni = (uint64_t)j.n * j.W;
-    uint32_t nc = (uint32_t)((ni + MSM_CHUNK - 1) / MSM_CHUNK);
+    uint32_t nc = (uint32_t)((ni + chunk - 1) / chunk);
     items += ni;
     chunks += nc;
     pairs += j.n;
@@ -983,7 +990,7 @@ static int msm_run_bucket_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs
   ZK_ALLOC(ctx, RC, G1X, (size_t)nj * reduce_shape(c).nsums);
   size_t lds = (size_t)(B + 2 + 1024) * 4;
   ZK_LAUNCH(ctx, "msm_sort", 32ull * pairs + 4ull * items, k_msm_sort, dim3(nj), dim3(1024), lds, (const MsmJob*)djobs.get(), c, K, idx.get(), off.get());
-  ZK_LAUNCH(ctx, "msm_accum", 100ull * items, k_msm_accum, dim3((max_chunks + 63) / 64, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, (const uint32_t*)idx.get(),
+  ZK_LAUNCH(ctx, "msm_accum", 100ull * items, k_msm_accum, dim3((max_chunks + 63) / 64, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, chunk, (const uint32_t*)idx.get(),
             (const uint32_t*)off.get(), buckets.get(), head.get(), tail.get());
   {
     // Full-width scalars: the top window holds 256 - c*(Wmax-1) bits, of which a folded scalar (< 2^254) fills two
@@ -992,10 +999,10 @@ static int msm_run_bucket_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs
     const bool full = c * Wmax >= 254u;
     const bool hot = !full || 256u - c * (Wmax - 1) <= 4u || chunks > 12ull * nj * B;  // or simply many chunks per bucket
     if (hot)
-      ZK_LAUNCH(ctx, "msm_combine", (uint64_t)sizeof(G1X) * nj * B, k_msm_combine<4>, dim3((B + 15) / 16, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, (const uint32_t*)off.get(),
+      ZK_LAUNCH(ctx, "msm_combine", (uint64_t)sizeof(G1X) * nj * B, k_msm_combine<4>, dim3((B + 15) / 16, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, chunk, (const uint32_t*)off.get(),
                 buckets.get(), (const G1X*)head.get(), (const G1X*)tail.get());
     else
-      ZK_LAUNCH(ctx, "msm_combine", (uint64_t)sizeof(G1X) * nj * B, k_msm_combine<2>, dim3((B + 31) / 32, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, (const uint32_t*)off.get(),
+      ZK_LAUNCH(ctx, "msm_combine", (uint64_t)sizeof(G1X) * nj * B, k_msm_combine<2>, dim3((B + 31) / 32, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, chunk, (const uint32_t*)off.get(),
                 buckets.get(), (const G1X*)head.get(), (const G1X*)tail.get());
   }
   const ReduceShape sh = reduce_shape(c);
