@@ -335,8 +335,8 @@ def spawn_ranks(n, argv):
             if pr.returncode not in (None, 0) and rc == 0:
                 rc = pr.returncode
         out0.seek(0)
-        sys.stdout.write(out0.read().decode(errors="replace"))
-        sys.stdout.flush()
+        OUT.write(out0.read().decode(errors="replace"))      # rank 0's line (its own stdout is already clean of library banners)
+        OUT.flush()
     return rc
 
 
@@ -385,19 +385,20 @@ def run_sharded(args, zk, dims, batch, rank, world, dist):
         elapsed = float(t.item())
     ms = elapsed * 1e3 / max(args.steps, 1)
     if rank == 0:
-        print(json.dumps({"metric": "proving ms/example (batch 256) on 18M-param MLP", "value": ms / batch, "unit": "ms/example", "n_gpus": world, "steps": args.steps,
+        OUT.write(json.dumps({"metric": "proving ms/example (batch 256) on 18M-param MLP", "value": ms / batch, "unit": "ms/example", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
                           "dtype": "u32x8 (Fr) / u32x12 (Fp) limbs", "data": "synthetic",
                           "config": {"workload": args.workload, "dims": dims, "batch_total": batch, "rows_per_gpu": per,
                                      "parallelism": "one proof sharded by batch rows; two all-gathers per proof (zkdl_amd/shard.py)"},
                           "transcript_values": [int(fr.shape[0]), int(aff.shape[0])],
-                          "transcript_sha256": __import__("hashlib").sha256(fr.tobytes() + aff.tobytes() + inf.tobytes()).hexdigest()}))
-        sys.stdout.flush()
+                          "transcript_sha256": __import__("hashlib").sha256(fr.tobytes() + aff.tobytes() + inf.tobytes()).hexdigest()}) + "\n")
+        OUT.flush()
     if world > 1:
         dist.destroy_process_group()
     zk.close()
 
 
+OUT = sys.stdout            # where the ONE line goes; main() points it at a private copy of fd 1 and sends everything else written to fd 1 to stderr
 LINE_LIMIT = 4096           # the driver keeps an 8 KB tail of stdout and parses its last line: the line has to fit with room to spare (BENCH_r03 did not)
 
 
@@ -482,8 +483,8 @@ def emit(out, detail_path):
         line["config"].pop("dims", None)
         text = json.dumps(line, separators=(",", ":"))
     assert len(text) < LINE_LIMIT, "bench line of %d bytes" % len(text)
-    print(text)
-    sys.stdout.flush()
+    OUT.write(text + "\n")
+    OUT.flush()
 
 
 def main():
@@ -534,6 +535,12 @@ def main():
                     help="CPU-only check of the N-rank launch path (tests/test_dist_aggregate.py): gloo all-reduce of per-rank digests, no GPU work; "
                          "FAIL_RANK >= 0 makes that rank exit with status 3 before the rendezvous")
     args = ap.parse_args()
+    # stdout carries ONE JSON line and nothing else: libraries that print there (RCCL's version banner at communicator creation, seen in the one-rank
+    # rehearsal) are sent to stderr at the file-descriptor level; the line is written to a private copy of the original fd 1
+    global OUT
+    sys.stdout.flush()
+    OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     # The first compute process on a freshly leased box runs ~12 % slow for its whole lifetime (5.2 vs 4.6 ms per proof over 20 steps;
     # any later process is not affected).  A 0.1 s helper (zkdl_amd/lib/gpu_touch: malloc, one kernel, exit) takes that role, BEFORE
@@ -589,7 +596,8 @@ def main():
         seen = [None] * world
         dist.all_gather_object(seen, rank)
         if rank == 0:
-            print(json.dumps({"selftest": True, "n_gpus": world, "collective_world_size": dist.get_world_size(), "aggregate_fr": hex(agg), "ranks": sorted(seen)}))
+            OUT.write(json.dumps({"selftest": True, "n_gpus": world, "collective_world_size": dist.get_world_size(), "aggregate_fr": hex(agg), "ranks": sorted(seen)}) + "\n")
+            OUT.flush()
         dist.destroy_process_group()
         return
     if args.same_device:

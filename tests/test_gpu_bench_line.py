@@ -44,3 +44,24 @@ def test_bench_line_keeps_the_contract(tmp_path):
     p = d["parity_checked"]
     assert p["ok"] is True and p["mismatch"] == [] and p["fr"] > 0 and p["g1"] > 0 and p["calls"] > 0
     assert d["latency_ms_per_proof"] > 0 and d["collective_world_size"] == 1
+
+
+def test_launcher_path_with_rccl_on_one_rank(tmp_path):
+    """The multi-GPU path as far as a one-GPU box can take it: `--spawn` starts the rank as a child process (the parent never touches the GPU, relays
+    rank 0's line, propagates its status) and `--collective --backend nccl` creates the RCCL process group and runs the aggregate's all-reduce on the
+    single rank.  Same run aggregate as the in-process, collective-free run of the same steps.  (N > 1 needs N devices; the driver's 8-GPU run is the
+    first time more than one rank meets.)"""
+    common = ["--workload", "tiny", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--steady-steps", "0", "--latency-reps", "0", "--ext-steps", "0", "--no-msm-probe",
+              "--no-prewarm"]
+    runs = []
+    for extra in (["--spawn", "--collective", "--backend", "nccl"], []):
+        run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--detail-out", str(tmp_path / "d.json")] + common + extra,
+                             capture_output=True, text=True, cwd=ROOT, timeout=600)
+        assert run.returncode == 0, run.stderr[-2000:]
+        lines = [ln for ln in run.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1 and len(lines[0]) < 4096
+        runs.append(json.loads(lines[0]))
+    spawned, plain = runs
+    assert spawned["collective_backend"] == "nccl" and spawned["collective_world_size"] == 1 and spawned["n_gpus"] == 1
+    assert plain.get("collective_backend") is None
+    assert spawned["aggregate_fr"] == plain["aggregate_fr"]
