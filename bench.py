@@ -342,7 +342,7 @@ def spawn_ranks(n, argv):
 
 def run_sharded(args, zk, dims, batch, rank, world, dist):
     """--mode shard: ONE batch-`batch` proof per step, its rows split over the ranks (strong scaling)."""
-    from zkdl_amd.shard import Shard, dist_allgather, prove_sharded
+    from zkdl_amd.shard import Shard, dist_allgather, prove_sharded, prove_sharded_stream
     import torch
     per = batch // world
     shard = Shard(Workload(zk, dims, batch, seed=0, rows=(rank * per, (rank + 1) * per)), rank, world)
@@ -371,12 +371,24 @@ def run_sharded(args, zk, dims, batch, rank, world, dist):
         if world > 1:
             dist.barrier()
 
-    for i in range(args.warmup):
-        prove_sharded([shard], challenges(-1 - i), gather)
+    # software-pipelined: three proofs in flight, every phase a sealed transcript (zkdl_amd/shard.py: prove_sharded_stream); --no-pipeline: one proof
+    # at a time, three host reads each
+    stream_gather = None if world == 1 else dist_allgather
+    if args.no_pipeline:
+        for i in range(args.warmup):
+            prove_sharded([shard], challenges(-1 - i), gather)
+    else:
+        for _ in prove_sharded_stream(shard, [challenges(-1 - i) for i in range(args.warmup)], stream_gather):
+            pass
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        fr, aff, inf = prove_sharded([shard], challenges(i), gather)
+    if args.no_pipeline:
+        for i in range(args.steps):
+            fr, aff, inf = prove_sharded([shard], challenges(i), gather)
+    else:
+        chals = (challenges(i) for i in range(args.steps))
+        for fr, aff, inf in prove_sharded_stream(shard, chals, stream_gather):
+            pass
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -389,7 +401,7 @@ def run_sharded(args, zk, dims, batch, rank, world, dist):
                           "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
                           "dtype": "u32x8 (Fr) / u32x12 (Fp) limbs", "data": "synthetic",
                           "config": {"workload": args.workload, "dims": dims, "batch_total": batch, "rows_per_gpu": per,
-                                     "parallelism": "one proof sharded by batch rows; two all-gathers per proof (zkdl_amd/shard.py)"},
+                                     "parallelism": "one proof sharded by batch rows; two all-gathers per proof (zkdl_amd/shard.py)", "proofs_in_flight": 1 if args.no_pipeline else 3},
                           "transcript_values": [int(fr.shape[0]), int(aff.shape[0])],
                           "transcript_sha256": __import__("hashlib").sha256(fr.tobytes() + aff.tobytes() + inf.tobytes()).hexdigest()}) + "\n")
         OUT.flush()

@@ -61,3 +61,28 @@ def test_mlp18m_batch256_sharded_over_8(zk):
     shards = [Shard(bench.Workload(zk, dims, batch, seed=2, rows=(32 * r, 32 * r + 32)), r, 8) for r in range(8)]
     fr_s, aff_s, inf_s = prove_sharded(shards, chal)
     assert np.array_equal(fr_s, fr) and np.array_equal(aff_s, aff) and np.array_equal(inf_s, inf)
+
+
+@pytest.mark.parametrize("dims,batch", [([40, 24, 12], 8), ([64, 96, 48, 32], 16)])
+def test_pipelined_sharded_stream_equals_the_sequential_one(zk, dims, batch):
+    """prove_sharded_stream keeps three sharded proofs in flight (every phase a sealed transcript, one read per phase waits for that transcript
+    only): each proof it yields is the single-GPU transcript of its own challenges, bit for bit, in order."""
+    import bench
+    from zkdl_amd.capi import Transcript
+    from zkdl_amd.shard import Shard, prove_sharded, prove_sharded_stream
+    whole = bench.Workload(zk, dims, batch, seed=11)
+    chals = [whole.challenges(st) for st in range(7)]
+    want = []
+    tr = Transcript(zk)
+    for ch in chals:
+        whole.prove(ch, tr)
+        want.append((tr.read()[0], tr.read_affine()))
+    tr.close()
+    shard = Shard(whole, 0, 1)
+    got = list(prove_sharded_stream(shard, chals))
+    assert len(got) == len(chals)
+    for (fr, aff, inf), (fr_w, (aff_w, inf_w)) in zip(got, want):
+        assert np.array_equal(fr, fr_w) and np.array_equal(aff, aff_w) and np.array_equal(inf, inf_w)
+    # and the unpipelined form still agrees
+    fr, aff, inf = prove_sharded([shard], chals[3])
+    assert np.array_equal(fr, want[3][0]) and np.array_equal(aff, want[3][1][0])

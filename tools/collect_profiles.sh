@@ -9,7 +9,7 @@ out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
 # profiler passes: no helper processes (they would inherit the profiler's preload and be traced into the same directory), no side measurements
-B="python3 bench.py --detail-out \"\" --no-cpu-baseline --no-msm-probe --no-prewarm --steady-steps 0 --ext-steps 0 --latency-reps 0 --spinup-ms 0"
+B="python3 bench.py --detail-out /dev/null --no-cpu-baseline --no-msm-probe --no-prewarm --steady-steps 0 --ext-steps 0 --latency-reps 0 --spinup-ms 0"
 timeout -k 10 900 python3 bench.py --detail-out $out/bench_detail.json > $out/bench.json 2> $out/bench.err
 echo "bench done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_serial -o kt -- $B --serial --steps 5 --warmup 2 > $out/kt_serial.log 2>&1

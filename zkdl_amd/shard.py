@@ -52,6 +52,7 @@ class Shard:
     def __init__(self, wl, rank, world):
         self.wl, self.rank, self.world, self.zk = wl, rank, world, wl.zk
         self.lw = ceil_log2(world)
+        self._chal_fc = {c: i for c, (kind, i) in enumerate(call_order(len(wl.shapes))) if kind == "fc"}   # call index -> layer of the zkFC calls
         if 1 << self.lw != world or wl.B_p * world != (1 << ceil_log2(wl.B_p * world)):
             raise ValueError("world size and the local batch must be powers of two")
 
@@ -60,12 +61,20 @@ class Shard:
         """All ReLU calls of the proof on this rank's rows, recorded into ONE transcript (so they run zipped across layers
         like an unsharded proof), plus the batch-side contractions of every zkFC call."""
         from .capi import Transcript
+        tr = Transcript(self.zk)
+        out = self.local_collect(self.local_enqueue(chal, tr), tr)
+        tr.close()
+        return out
+
+    def local_enqueue(self, chal, tr):
+        """The device side of phase 1, without a host wait: the contractions are launched, the ReLU calls recorded on `tr`, and `tr` is SEALED --
+        its launches run while the caller enqueues or collects other proofs (prove_sharded_stream)."""
         wl, zk = self.wl, self.zk
-        sh, L = wl.shapes, len(wl.shapes)
+        sh = wl.shapes
         kb_l = ceil_log2(wl.B_p)
         out = []
-        tr = Transcript(zk)
         relu_lens_seen = []
+        tr.reset()
         # the batch-side contractions first (immediate launches: an immediate call settles recorded work, which would cut the ReLU
         # calls' recorded chains apart), then every ReLU call recorded on one transcript, then ONE read
         a_dev = {}
@@ -84,8 +93,14 @@ class Shard:
                 wl.relus[i].prove(wl.Z[i], wl.A[i], [c_[:n] for c_, n in zip(ch, lens)], tr)
                 relu_lens_seen.append(3 * (k_l + 5) + 1 + 32 + 3 * (k_l + 4) + 1 + 16 + 3 * k_l + 2)
                 out.append(dict(fr=None))
+        tr.seal()
+        return out, relu_lens_seen
+
+    def local_collect(self, state, tr, keep_on_device=False):
+        """The host side of phase 1: ONE read of the sealed transcript (waits for that transcript only).  keep_on_device (a single rank: nothing
+        crosses a process boundary): the contracted vectors stay where they are."""
+        out, relu_lens_seen = state
         fr, _ = tr.read()
-        tr.close()
         off = 0
         it = iter(relu_lens_seen)
         for part in out:
@@ -93,7 +108,7 @@ class Shard:
                 n = next(it)
                 part["fr"] = fr[off:off + n].copy()
                 off += n
-            else:
+            elif not keep_on_device:
                 part["a"] = part["a"].download()
         return out
 
@@ -104,18 +119,27 @@ class Shard:
         Z~(u_out || u_bs) = (a W)~(u_out), so Z's stand-in is the layer applied to a (un-Montgomery'd for the last layer,
         demo.cu:119).  The inner-product sumcheck and the opening never see the batch."""
         from .capi import Transcript
+        tr = Transcript(self.zk)
+        out = self.owner_collect(self.owner_enqueue(chal, gathered, tr), tr)
+        tr.close()
+        return out
+
+    def owner_enqueue(self, chal, gathered, tr):
+        """The device side of phase 2 without a host wait (sealed, like local_enqueue)."""
         zk, wl = self.zk, self.wl
-        sh, L = wl.shapes, len(wl.shapes)
+        L = len(wl.shapes)
         mine = [c for c, (kind, i, ch) in enumerate(chal) if kind == "fc" and i % self.world == self.rank]
+        tr.reset()
         if not mine:
-            return {}
-        tr = Transcript(zk)
+            return mine, []
         keep = []
         for c in mine:                       # the stand-ins first (immediate launches) ...
             _, i, _ = chal[c]
             a = None
             for r in range(self.world):
-                ar = zk.upload(gathered[r][c]["a"])
+                ar = gathered[r][c]["a"]
+                if isinstance(ar, np.ndarray):
+                    ar = zk.upload(ar)
                 a = ar if a is None else zk.fr_add(a, ar)
             z = wl.fcs[i].forward(a)
             if i == L - 1:
@@ -124,12 +148,20 @@ class Shard:
         for c, (a, z) in zip(mine, keep):    # ... then every owned layer recorded on one transcript: zipped like an unsharded proof
             _, i, (u_bs, u_in, u_out) = chal[c]
             wl.fcs[i].prove(a, z, wl.gens[i], u_bs[:0], u_in, u_out, tr)
+        tr.seal()
+        return mine, keep                    # `keep` holds the stand-ins alive until the sealed phase has been read
+
+    def owner_collect(self, state, tr):
+        mine, _keep = state
+        if not mine:
+            return {}
+        sh = self.wl.shapes
+        chal_fc = self._chal_fc
         fr, _ = tr.read()
         aff, inf = tr.read_affine()
-        tr.close()
         out, of, og = {}, 0, 0
         for c in mine:
-            s = sh[chal[c][1]]
+            s = sh[chal_fc[c]]
             nf, ng = 3 * ceil_log2(s["in_p"]) + 4, 3 * ceil_log2(s["n_gens"]) + 2
             out[c] = dict(fr=fr[of:of + nf].copy(), aff=aff[og:og + ng].copy(), inf=inf[og:og + ng].copy())
             of += nf
@@ -241,6 +273,41 @@ def prove_sharded(shards, chal, allgather=None):
     for part in allgather(sh.owner_phase(chal, gathered)):
         owned.update(part)
     return sh.assemble(chal, gathered, owned)
+
+
+def prove_sharded_stream(shard, chals, allgather=None, inflight=3):
+    """K sharded proofs, software-pipelined: while proof k's first phase is being read, proof k + 1's first phase and proof k - 1's second phase
+    are already on the device (every phase is a SEALED transcript: a read waits for that transcript only), so the three host reads per proof
+    no longer leave the GPU idle.  `shard`: this process's Shard; `allgather` as in prove_sharded (None: a single rank, payloads stay on the device).
+    Yields (Fr, affine G1, infinity flags) per proof, in order -- each the single-GPU transcript of that proof's challenges, bit for bit."""
+    from .capi import Transcript
+    single = allgather is None
+    if single:
+        if shard.world != 1:
+            raise ValueError("prove_sharded_stream without a collective is the one-rank form")
+        allgather = lambda obj: [obj]
+    trsA = [Transcript(shard.zk) for _ in range(inflight)]
+    trsB = [Transcript(shard.zk) for _ in range(inflight)]
+    chals = list(chals)
+    K = len(chals)
+    stA, stB, gathered = {}, {}, {}
+    try:
+        for k in range(K + 2):
+            if k < K:
+                stA[k] = shard.local_enqueue(chals[k], trsA[k % inflight])
+            j = k - 1
+            if 0 <= j < K:
+                gathered[j] = allgather(shard.local_collect(stA.pop(j), trsA[j % inflight], keep_on_device=single))
+                stB[j] = shard.owner_enqueue(chals[j], gathered[j], trsB[j % inflight])
+            j = k - 2
+            if 0 <= j < K:
+                owned = {}
+                for part in allgather(shard.owner_collect(stB.pop(j), trsB[j % inflight])):
+                    owned.update(part)
+                yield shard.assemble(chals[j], gathered.pop(j), owned)
+    finally:
+        for t in trsA + trsB:
+            t.close()
 
 
 def dist_allgather(obj):
