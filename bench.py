@@ -458,7 +458,8 @@ def compact_line(out):
     if bm:
         line["g1_msm_mops_bucket_method"] = bm["mops"]
     ext = out.get("extensions") or {}
-    for k, short in (("sound_mode_round_by_round_fiat_shamir", "sound_mode_ms_per_proof"), ("activation_openings_in_proof", "act_openings_ms_per_proof")):
+    for k, short in (("sound_mode_round_by_round_fiat_shamir", "sound_mode_ms_per_proof"), ("activation_openings_in_proof", "act_openings_ms_per_proof"),
+                     ("activation_commitments_and_openings_streamed", "act_commitments_and_openings_ms_per_proof")):
         if k in ext:
             line[short] = ext[k]["steady_state_ms_per_proof"]
     line["value_is"] = "pipelined throughput: wall of K proofs / K / batch; latency_ms_per_proof = ONE synchronous prove loop (demo.cu:124-140)"
@@ -837,6 +838,24 @@ def main():
             extensions["sound_mode_round_by_round_fiat_shamir" if which == "fs" else "activation_openings_in_proof"] = {
                 "steady_state_ms_per_proof": (t_long - t_short) / (n_long - n_short), "latency_ms_per_proof": float(np.median(one)),
                 "runs_ms": {str(n_short): t_short, str(n_long): t_long}}
+        # the activation commitments themselves as part of the pipeline (zk_act_commit: deferred row MSMs on the digit tables, two sealed stages per proof,
+        # three proofs in flight; zkdl_amd/proof.py: prove_with_activation_commitments_stream)
+        from zkdl_amd.proof import prove_with_activation_commitments_stream
+
+        def run_actc(n):
+            zk.sync()
+            t = time.perf_counter()
+            for _ in prove_with_activation_commitments_stream(zk, dims, batch, wl.gens, wl.fcs, wl.relus, wl.X, wl.Z, wl.A, wl.Yhat, seed_, n):
+                pass
+            zk.sync()
+            return (time.perf_counter() - t) * 1e3
+
+        run_actc(3)
+        n_short, n_long = max(2, args.ext_steps // 4), max(4, args.ext_steps // 2)
+        t_short, t_long = run_actc(n_short), run_actc(n_long)
+        extensions["activation_commitments_and_openings_streamed"] = {"steady_state_ms_per_proof": (t_long - t_short) / (n_long - n_short),
+                                                                     "latency_ms_per_proof": run_actc(1), "runs_ms": {str(n_short): t_short, str(n_long): t_long},
+                                                                     "what": "per proof: 14 row-wise commitments of the 2^18 .. 2^19-entry activation tensors + the layer proofs + 7 reductions and openings"}
         extensions["note"] = ("same workload, same pipelined loop as the headline (derive_rounds / g1_batch / inflight as configured); the headline itself is the "
                               "reference-parity mode (pre-drawn challenges, no activation commitments), which is what the reference times")
     # ---- the proof the CPU oracle is compared with: made in the benchmarked configuration, with len(trs) proofs in flight around it
@@ -948,7 +967,9 @@ def main():
             # then one addition per product into its T_r
             macs_per_step["msm_derive"] = n_derived * (2 * (128 * JDBL + 32 * JADD + JDBL + 6 * JADD) + JADD + JADD) * FP_MACS
         if "g1_canonicalise" in prof:
-            macs_per_step["g1_canonicalise"] = n_g1_out * (INV + 5) * FP_MACS         # 1/Z, Z^-2, Z^-3, x, y
+            # 1/Z by binary GCD (fpinv.hpp: 25 groups x ten 12-limb multiply-accumulate rows, no field products) + the two domain conversions, the R^3
+            # product, Z^-2, Z^-3, x, y and their conversions back
+            macs_per_step["g1_canonicalise"] = n_g1_out * (25 * 10 * 12 + 10 * FP_MACS)
     # the newest counter summary under profiles/ (tools/collect_profiles.sh + tools/pmc_summary.py: separate rocprofv3 --pmc passes of this bench).
     # It records the fingerprint of the sources it was collected from; if this tree differs, the traffic figure is flagged stale.
     import glob as _glob

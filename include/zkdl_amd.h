@@ -346,6 +346,10 @@ int zk_field_selftest(zk_ctx* ctx, int which, int op, const void* a_d, const voi
  * holds the tensor, and the generators' window tables exist).  One sumcheck and one opening per hidden layer instead of three openings. */
 int zk_act_open(zk_ctx* ctx, zk_gens* gens, const zk_fr* z_d, const zk_fr* a_d, uint32_t n, const zk_fr* pts_h, const zk_fr* alpha_h, const zk_fr* fold_h,
                 zk_transcript* tr);
+/* Commitment::commit (the intended row MSM, as zk_commit) deferred into a transcript: appends the tn / n_gens points to tr's G1 list; the MSMs join the
+ * transcript's batch (digit tables when present), so a sealed transcript computes them under other proofs' work.  Used for the per-input activation
+ * commitments com(Z_i), com(A_i) (zkdl_amd/proof.py: prove_with_activation_commitments_stream). */
+int zk_act_commit(zk_ctx* ctx, zk_gens* gens, const zk_fr* t_d, uint32_t tn, zk_transcript* tr);
 /* The same with the reduction's challenges bound to the prover's messages (the sound mode of the layer proofs, zk_*_prove_fs): alpha =
  * zk_fs_derive(seed32, layer, 2, 0, 1) and every ROUND challenge -- hence the opening point r' -- is the hash chain of zk_fs_round_challenges with
  * kind = 2, which = 0 over the reduction's own round messages, computed on the device.  seed32 must absorb everything alpha may depend on: the

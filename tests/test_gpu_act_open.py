@@ -222,3 +222,52 @@ def test_sound_layer_proofs_with_hashed_activation_openings(zk, oracle, dims, ba
     ok, msg, _ = verify_mlp_with_activation_openings(*args, blobs[1][1], chal=chal)
     assert ok, msg
     tr.close()
+
+
+@pytest.mark.parametrize("dims,batch,tables", [([16, 32, 24, 8], 4, 0), ([40, 70, 30], 20, 8), ([600, 900, 700, 300], 64, 0)])
+def test_activation_commitments_inside_the_pipeline(zk, oracle, dims, batch, tables):
+    """the per-input activation commitments as part of the proving pipeline.  zk_act_commit defers the row MSMs of com(Z_i), com(A_i) into a
+    transcript (digit tables when the generators have them); prove_with_activation_commitments_stream keeps two sealed stages per proof and three
+    proofs in flight.  The points equal zk_commit's (affine-canonical), every streamed proof verifies against them, a proof made for other
+    commitments does not, and all proofs of one statement are identical."""
+    from mlp_util import setup_mlp_gpu, synth_mlp
+    from zkdl_amd.capi import Transcript
+    from zkdl_amd.proof import act_coms_from_points, prove_with_activation_commitments_stream, statement_digest, verify_mlp_with_activation_openings
+    model = synth_mlp(oracle, dims, batch, seed=91)
+    st = setup_mlp_gpu(zk, model)
+    if tables:
+        for g in st["gens"]:
+            g.prepare_full(tables)
+    coms = [fc.com() for fc in st["fcs"]]
+    seed = statement_digest(zk, dims, batch, st["gens"], coms, st["X"], st["Yhat"])
+    # the deferred commitment == the synchronous one
+    tr = Transcript(zk)
+    for i in range(len(dims) - 2):
+        zk.act_commit(st["gens"][i], st["Z"][i], tr)
+        zk.act_commit(st["gens"][i], st["A"][i], tr)
+    aff, inf = tr.read_affine()
+    want = concat_coms(zk, st["gens"], st["Z"], st["A"])
+    og = 0
+    for w in want:
+        wa, wi = zk.g1_to_affine(w)
+        assert np.array_equal(aff[og:og + w.n], wa) and np.array_equal(inf[og:og + w.n], wi)
+        og += w.n
+    assert og == aff.shape[0]
+    tr.close()
+    # the streamed prover
+    got = list(prove_with_activation_commitments_stream(zk, dims, batch, st["gens"], st["fcs"], st["relus"], st["X"], st["Z"], st["A"], st["Yhat"], seed, 5))
+    assert len(got) == 5
+    args = lambda ac: (zk, dims, batch, st["gens"], coms, ac, st["X"], st["Yhat"])
+    for a_k, i_k, blob in got:
+        assert np.array_equal(a_k, aff) and np.array_equal(i_k, inf) and blob == got[0][2]
+    act_coms = act_coms_from_points(zk, dims, batch, got[2][0], got[2][1])
+    ok, msg, remaining = verify_mlp_with_activation_openings(*args(act_coms), got[2][2])
+    assert ok, msg
+    assert len(remaining) == 4 * (len(dims) - 2)
+    ok2, msg2, _ = verify_mlp_with_activation_openings(*args(want), got[4][2])          # the same points, uploaded as zk_commit returned them
+    assert ok2, msg2
+    if len(dims) >= 4 and want[0].n == want[1].n:
+        assert not verify_mlp_with_activation_openings(*args([want[1], want[0]] + want[2:]), got[0][2])[0]
+    bad = bytearray(got[0][2])
+    bad[-40] ^= 1
+    assert not verify_mlp_with_activation_openings(*args(act_coms), bytes(bad))[0]

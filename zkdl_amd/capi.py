@@ -35,7 +35,7 @@ zk_fc_out zk_fc_com_size zk_fc_weights zk_fc_com zk_fc_load_input zk_fc_forward 
 zk_relu_destroy zk_relu_forward zk_relu_sign zk_relu_mag_bin zk_relu_rem_bin zk_relu_prove zk_transcript_create
 zk_transcript_destroy zk_transcript_reset zk_transcript_flush zk_transcript_counts zk_transcript_read zk_transcript_read_affine
 zk_transcript_digest zk_transcript_digest_dev zk_transcript_serialize zk_transcript_seal zk_transcript_seal_pair zk_transcript_stream
-zk_verify_fc zk_verify_relu zk_verify_open zk_fs_derive zk_sha256 zk_fc_prove_fs zk_relu_prove_fs zk_leaky_prove_fs zk_fs_round_challenges zk_relu_set_activation zk_leaky_prove zk_verify_leaky zk_act_open zk_act_open_fs zk_verify_act_open zk_dist_unique_id zk_dist_init zk_dist_world_size zk_dist_sum_rows zk_dist_allreduce_u64
+zk_verify_fc zk_verify_relu zk_verify_open zk_fs_derive zk_sha256 zk_fc_prove_fs zk_relu_prove_fs zk_leaky_prove_fs zk_fs_round_challenges zk_relu_set_activation zk_leaky_prove zk_verify_leaky zk_act_open zk_act_open_fs zk_act_commit zk_verify_act_open zk_dist_unique_id zk_dist_init zk_dist_world_size zk_dist_sum_rows zk_dist_allreduce_u64
 zk_dist_lanes_to_fr zk_dist_destroy zk_gens_prepare_full zk_field_selftest""".split()
 
 
@@ -523,6 +523,10 @@ class Zk:
         if pts.shape[0] != 3 * k or fold.shape[0] != k + 1:
             raise ShapeError(ZK_ERR_SHAPE, "Incompatible dimensions")
         self._chk(self.lib.zk_act_open(self.ctx, gens.h, _vp(z.ptr), _vp(a.ptr), _u32(z.n), _hp(_fr_host(pts)), _hp(_fr_host(alpha, 1)), _hp(fold), tr.h))
+
+    def act_commit(self, gens, t, tr):
+        """zk_act_commit: the row-wise commitment of tensor t over gens, deferred into tr (t.n / gens.n points appended to its G1 list)."""
+        self._chk(self.lib.zk_act_commit(self.ctx, gens.h, _vp(t.ptr), _u32(t.n), tr.h))
 
     def act_open_fs(self, gens, z, a, pts, seed32, layer, tr):
         """zk_act_open_fs: the same with alpha and the reduction's round challenges hashed from seed32 and the reduction's own round messages."""

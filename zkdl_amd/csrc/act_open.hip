@@ -186,6 +186,32 @@ int zk_act_open(zk_ctx* ctx, zk_gens* gens, const zk_fr* z_d, const zk_fr* a_d, 
   return guard.finish(act_open_body(ctx, gens, reinterpret_cast<const Fr*>(z_d), reinterpret_cast<const Fr*>(a_d), n, pts_h, alpha_h, fold_h, tr));
 }
 
+// Row-wise commitment of a tensor (Commitment::commit's intended row MSM, commitment.cu:29-41, as zk_commit computes it) DEFERRED into a transcript: the
+// tn / n_gens commitment points are appended to tr's G1 list and their MSMs join the transcript's batch -- on the digit tables when the generator set
+// has them (a zero digit costs nothing there, so short scalars such as activations pay for their non-zero windows only), and a sealed transcript runs them
+// under other proofs' work.  This is what makes the activation commitments part of the proving pipeline instead of a synchronous setup call per tensor.
+int zk_act_commit(zk_ctx* ctx, zk_gens* gens, const zk_fr* t_d, uint32_t tn, zk_transcript* tr) {
+  if (!ctx) return ZK_ERR_ARG;
+  (void)hipSetDevice(ctx->device);
+  if (!gens || !t_d || !tr) return ctx->fail(ZK_ERR_ARG, "zk_act_commit: null argument");
+  if (((uintptr_t)t_d) & 15u) return ctx->fail(ZK_ERR_ARG, "misaligned device pointer");
+  const uint32_t n = gens->n;
+  if (n == 0 || tn == 0 || tn % n) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");   // commitment.cu:31
+  const uint32_t m = tn / n;
+  ActGuard guard(ctx, tr);
+  auto body = [&]() -> int {
+    ZK_TRY(tr->ensure(0, m));
+    G1J* const slot = tr->g1_d + tr->n_g1;
+    tr->n_g1 += m;
+    RecScope recording(ctx, &tr->rec, REC_GROUP_FC_OPEN);
+    if (recording.rc != ZK_OK) return recording.rc;
+    rec_split(ctx, REC_GROUP_FC_OPEN, /*early=*/true);   // scalar preparation only: the G1 phase may start behind it
+    LaneScope lane(ctx, recording.on ? ~0u : 0u);
+    return msm_enqueue(ctx, gens, reinterpret_cast<const Fr*>(t_d), m, /*do_unmont=*/true, /*probe_bits=*/false, slot, &tr->queue);
+  };
+  return guard.finish(body());
+}
+
 int zk_act_open_fs(zk_ctx* ctx, zk_gens* gens, const zk_fr* z_d, const zk_fr* a_d, uint32_t n, const zk_fr* pts_h, const uint8_t* seed32, uint32_t layer, zk_transcript* tr) {
   if (!ctx) return ZK_ERR_ARG;
   (void)hipSetDevice(ctx->device);

@@ -435,3 +435,87 @@ def verify_mlp_with_activation_openings(zk, dims, batch, gens, coms, act_coms, x
         of += nf
         og += ng
     return True, "", [(k, v) for k, v in open_claims if k not in closed]
+
+
+# ------------------------------------------------------------------ activation commitments made INSIDE the proving pipeline
+def act_commit_counts(dims, batch):
+    """Points per hidden layer of [com(Z_i) ; com(A_i)]: 2 m_i, m_i = B_p out_p / n_gens"""
+    sh = layer_shapes(dims)
+    B_p = 1 << ceil_log2(batch)
+    return [2 * (B_p * s["out_p"] // s["n_gens"]) for s in sh[:-1]]
+
+
+def act_seed_from_points(seed, dims, batch, aff, inf):
+    """act_statement_seed() from the affine-canonical commitment points as a transcript holds them (all hidden layers, [com(Z_i) ; com(A_i)] in order)"""
+    parts = [b"zkdl-amd/act/v1", bytes(seed)]
+    og = 0
+    for n in act_commit_counts(dims, batch):
+        parts += [sha256(np.ascontiguousarray(aff[og:og + n]).tobytes()), sha256(np.ascontiguousarray(inf[og:og + n]).tobytes())]
+        og += n
+    if og != aff.shape[0]:
+        raise ValueError("commitment transcript does not have the shape of this model")
+    return sha256(b"".join(parts))
+
+
+def prove_with_activation_commitments_stream(zk, dims, batch, gens, fcs, relus, X, Z, A, Yhat, seed, count, inflight=3):
+    """`count` proofs of one statement, each WITH its activation commitments, software-pipelined in two sealed stages per proof:
+        A: com(Z_i), com(A_i) of every hidden layer as deferred row MSMs (zk_act_commit) on their own transcript -- read back when they are done, because
+           the openings' challenges must depend on them (act_statement_seed);
+        B: the layer proofs (statement-derived challenges) and the activation openings (challenges from the seed that absorbed stage A's points).
+    While proof k's stage A is read, proof k + 1's stage A and proof k - 1's stage B are on the device: the commitments cost their MSM work
+    (7 M short-scalar products per 18M / batch-256 proof) but no idle time.  Yields (commitment points affine, their infinity flags, serialised stage-B proof)."""
+    from .capi import Transcript
+    chal = fs_challenges(seed, dims, batch)
+    L = len(dims) - 1
+    trsA = [Transcript(zk) for _ in range(inflight)]
+    trsB = [Transcript(zk) for _ in range(inflight)]
+    com = {}
+    try:
+        for k in range(count + 2):
+            if k < count:
+                t = trsA[k % inflight]
+                t.reset()
+                for i in range(L - 1):
+                    zk.act_commit(gens[i], Z[i], t)
+                    zk.act_commit(gens[i], A[i], t)
+                t.seal()
+            j = k - 1
+            if 0 <= j < count:
+                aff, inf = trsA[j % inflight].read_affine()
+                com[j] = (aff, inf)
+                aseed = act_seed_from_points(seed, dims, batch, aff, inf)
+                t = trsB[j % inflight]
+                t.reset()
+                fcs[L - 1].prove(A[L - 2] if L > 1 else X, Yhat, gens[L - 1], *[c for c in chal[0][2]], t)
+                for (kind, i, ch) in chal[1:]:
+                    if kind == "relu":
+                        relus[i].prove(Z[i], A[i], ch, t)
+                    else:
+                        fcs[i].prove(A[i - 1] if i > 0 else X, Z[i], gens[i], ch[0], ch[1], ch[2], t)
+                prove_activation_openings(zk, dims, batch, gens, Z, A, chal, aseed, t)
+                t.seal()
+            j = k - 2
+            if 0 <= j < count:
+                aff, inf = com.pop(j)
+                yield aff, inf, trsB[j % inflight].serialize()
+    finally:
+        for t in trsA + trsB:
+            t.close()
+
+
+def act_coms_from_points(zk, dims, batch, aff, inf):
+    """Device arrays [com(Z_i) ; com(A_i)] (Jacobian, Z = 1) per hidden layer from the affine points of a stage-A transcript: what
+    verify_mlp_with_activation_openings takes as act_coms."""
+    p_mod = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+    G1_ONE_MONT = np.frombuffer(((1 << 384) % p_mod).to_bytes(48, "little"), dtype=np.uint32)     # 1 in the library's Montgomery form
+    out, og = [], 0
+    for n in act_commit_counts(dims, batch):
+        a, f = aff[og:og + n], inf[og:og + n]
+        jac = np.zeros((n, 36), dtype=np.uint32)
+        jac[:, :24] = a
+        jac[:, 24:] = np.asarray(G1_ONE_MONT, dtype=np.uint32)
+        jac[f != 0] = 0
+        jac[f != 0, 12:24] = np.asarray(G1_ONE_MONT, dtype=np.uint32)      # infinity as {0, ONE, 0}
+        out.append(zk.upload(jac))
+        og += n
+    return out
