@@ -370,6 +370,18 @@ int fr_quant16_dev(zk_ctx* ctx, const Fr* t, uint32_t n, int16_t* q, uint32_t* o
   return ZK_OK;
 }
 
+// out[w] = sum_{m<M} x[m] * q[m*W + w]: a row vector of ARBITRARY field elements times the int16 copy of a quantised [M][W] matrix (M = 2^c <= 2^14:
+// a column of <= 2^14 products < 2^48 fits 64 bits).  The batch-1 forward pass of a layer on a folded activation vector (zkdl_amd/shard.py: the
+// owner's stand-in Z = a W) -- through the Montgomery matmul that was 4 M field products on a grid shaped for batches, ~1.5 ms per layer.
+int fr_vec_q16_dev(zk_ctx* ctx, const Fr* x, uint32_t M, const int16_t* q, uint32_t W, Fr* out) {
+  const uint32_t c = ceil_log2(M);
+  if (M == 0 || W == 0 || M != (1u << c) || c > 14) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
+  ZK_ALLOC(ctx, C, Acc9, 1);
+  ZK_LAUNCHB(ctx, "eq_table", 32ull * M, 64, k_q16_offset, dim3(1), 0, x, M, c, C.get());
+  ZK_LAUNCHB(ctx, "fr_contract_q16", 2ull * M * W + 32ull * (M + W), 256, k_colsum_q16, dim3(stream_grid(W)), 0, q, M * W, x, M, (const Acc9*)C.get(), W, W, out);
+  return ZK_OK;
+}
+
 // FrTensor::partial_me over the int16 copy of a quantised tensor: the first level (all the traffic) reads the
 // int16s, the remaining levels fold its Fr output exactly as fr_partial_me_dev does
 int fr_partial_me_q16_dev(zk_ctx* ctx, const int16_t* q, uint32_t n, const Fr* u_d, uint32_t k, uint32_t W, Fr* out_d) {

@@ -548,6 +548,8 @@ int fc_forward(zk_ctx* ctx, const zk_fc* fc, const Fr* x, uint32_t xn, Fr* z) {
   if (xn % fc->in != 0) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");  // zkfc.cu:118
   uint32_t batch = xn / fc->in;
   if (batch == 0) return ZK_OK;
+  if (fc->wq && batch == 1 && fc->in <= 16384 && (fc->in & (fc->in - 1)) == 0)  // one row of arbitrary field elements: no range check, no host round trip
+    return fr_vec_q16_dev(ctx, x, fc->in, fc->wq, fc->out, z);
   if (fc->wq && fc->in <= 16384) {  // quantised layer: exact int64 GEMM when the activations are small integers too
     ZK_ALLOC(ctx, xi, int64_t, xn);
     ZK_ALLOC(ctx, ovf, uint32_t, 1);

@@ -126,6 +126,7 @@ int fsb_sumcheck_head_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t 
 // holds the running hash state (fs_state0_slot writes its initial value on the host, before the upload)
 int sumcheck_ip_fs_dev(zk_ctx* ctx, const Fr* a, const Fr* b, uint32_t n, Fr* fold_state_d, uint32_t k, Fr* proof_d);
 void fs_state0_slot(const uint8_t seed32[32], uint32_t layer, uint32_t kind, uint32_t which, zk_fr* slot);
+int fr_vec_q16_dev(zk_ctx* ctx, const Fr* x, uint32_t M, const int16_t* q, uint32_t W, Fr* out);
 int float_to_fr_dev(zk_ctx* ctx, const float* fs, Fr* out, uint32_t rows, uint32_t rows_p, uint32_t cols, uint32_t cols_p);
 int gens_create(zk_ctx* ctx, const G1J* gens_d, uint32_t n, bool copy, zk_gens** out);
 void gens_destroy(zk_gens* g);
