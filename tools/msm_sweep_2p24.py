@@ -3,7 +3,7 @@
 4096 generators x 4096 rows = 2^24 (point, scalar) pairs, the shape of one width-4096 layer's commitment:
   * zk_msm_batch with FULL-WIDTH (uniform 255-bit) scalars, and
   * zk_commit with quantised-weight scalars (|w| < 2^13: what Commitment::commit sees, commitment.cu:29-41),
-HIP-event timed, window width c = 6 .. 16 (0 = the library's choice).  Prints a table; --json writes it as JSON."""
+HIP-event timed, window width c = 6 .. 13 (0 = the library's choice).  Prints a table; --json writes it as JSON."""
 import json
 import os
 import sys

@@ -43,6 +43,20 @@ for it in range(6):
     stB = timed("owner_enqueue", lambda: shard.owner_enqueue(c, g, trB), acc)
     own = timed("owner_collect", lambda: shard.owner_collect(stB, trB), acc)
     timed("assemble", lambda: shard.assemble(c, g, own), acc)
+# per-kernel device time of one owner phase (worker streams off: every launch alone)
+c = chal(99)
+stA = shard.local_enqueue(c, trA)
+g = [shard.local_collect(stA, trA, keep_on_device=True)]
+zk.sync()
+zk.set_flag("lanes", 0)
+zk.prof_reset(); zk.prof_enable(True)
+stB = shard.owner_enqueue(c, g, trB)
+zk.sync()
+p = zk.prof_read(); zk.prof_enable(False)
+zk.set_flag("lanes", 1)
+shard.owner_collect(stB, trB)
+for k, v in sorted(p.items(), key=lambda kv: -kv[1]["ms"])[:14]:
+    print("   owner phase  %-22s %8.3f ms  %4d launches" % (k, v["ms"], v["launches"]))
 for k, v in acc.items():
     v = v[2:]
     print("%-16s host %7.3f ms   host + device %7.3f ms" % (k, sum(a for a, _ in v) / len(v), sum(b for _, b in v) / len(v)))

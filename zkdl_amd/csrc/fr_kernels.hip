@@ -373,12 +373,51 @@ int fr_quant16_dev(zk_ctx* ctx, const Fr* t, uint32_t n, int16_t* q, uint32_t* o
 // out[w] = sum_{m<M} x[m] * q[m*W + w]: a row vector of ARBITRARY field elements times the int16 copy of a quantised [M][W] matrix (M = 2^c <= 2^14:
 // a column of <= 2^14 products < 2^48 fits 64 bits).  The batch-1 forward pass of a layer on a folded activation vector (zkdl_amd/shard.py: the
 // owner's stand-in Z = a W) -- through the Montgomery matmul that was 4 M field products on a grid shaped for batches, ~1.5 ms per layer.
+// Two launches: (w, slice of VQ_SLICE rows) -> 64-bit columns (x[m] uniform per wave: scalar loads), then per w the slices' sum, the offset, the reduction.
+static constexpr uint32_t VQ_SLICE = 64;
+__device__ __forceinline__ void k_vec_q16_part(uint32_t zk_nblk, const int16_t* __restrict__ q, const Fr* __restrict__ x, uint32_t M, uint32_t W, Col8* __restrict__ part) {
+  const uint32_t S = (M + VQ_SLICE - 1) / VQ_SLICE;
+  const __attribute__((address_space(4))) uint32_t* xc = (const __attribute__((address_space(4))) uint32_t*)x;
+  const __attribute__((address_space(1))) int16_t* qg = (const __attribute__((address_space(1))) int16_t*)q;
+  const uint32_t wblocks = (W + blockDim.x - 1) / blockDim.x;
+  for (uint32_t blk = blockIdx.x; blk < wblocks * S; blk += zk_nblk) {
+    const uint32_t sl = blk / wblocks, w = (blk - sl * wblocks) * blockDim.x + threadIdx.x;
+    if (w >= W) continue;
+    Col8 acc;
+    col8_zero(acc);
+    const uint32_t m1 = min(M, (sl + 1) * VQ_SLICE);
+    for (uint32_t m = sl * VQ_SLICE; m < m1; m++) {
+      const uint32_t u = (uint32_t)((int32_t)qg[(uint64_t)m * W + w] + 32768);
+      Fr e;
+#pragma unroll
+      for (int l = 0; l < 8; l++) e.v[l] = xc[8u * m + l];
+      col8_mac(acc, e, u);
+    }
+    part[(uint64_t)sl * W + w] = acc;
+  }
+}
+__device__ __forceinline__ void k_vec_q16_fin(uint32_t zk_nblk, const Col8* __restrict__ part, uint32_t S, uint32_t W, const Acc9* __restrict__ Cp, Fr* __restrict__ out) {
+  const Acc9 C = *Cp;
+  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < W; w += zk_nblk * blockDim.x) {
+    Col8 acc;
+    col8_zero(acc);
+    for (uint32_t sl = 0; sl < S; sl++) {
+      const Col8 p = part[(uint64_t)sl * W + w];
+#pragma unroll
+      for (int i = 0; i < 8; i++) acc.c[i] += p.c[i];
+    }
+    out[w] = acc9_reduce(acc9_add(col8_carry(acc), C));
+  }
+}
 int fr_vec_q16_dev(zk_ctx* ctx, const Fr* x, uint32_t M, const int16_t* q, uint32_t W, Fr* out) {
   const uint32_t c = ceil_log2(M);
   if (M == 0 || W == 0 || M != (1u << c) || c > 14) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");
+  const uint32_t S = (M + VQ_SLICE - 1) / VQ_SLICE;
   ZK_ALLOC(ctx, C, Acc9, 1);
+  ZK_ALLOC(ctx, part, Col8, (size_t)S * W);
   ZK_LAUNCHB(ctx, "eq_table", 32ull * M, 64, k_q16_offset, dim3(1), 0, x, M, c, C.get());
-  ZK_LAUNCHB(ctx, "fr_contract_q16", 2ull * M * W + 32ull * (M + W), 256, k_colsum_q16, dim3(stream_grid(W)), 0, q, M * W, x, M, (const Acc9*)C.get(), W, W, out);
+  ZK_LAUNCHB(ctx, "fr_contract_q16", 2ull * M * W + 32ull * M + 64ull * S * W, 64, k_vec_q16_part, dim3(stream_grid((uint64_t)S * W, 64, 4096)), 0, q, x, M, W, part.get());
+  ZK_LAUNCHB(ctx, "fr_contract_q16", 64ull * S * W + 32ull * W, 256, k_vec_q16_fin, dim3(stream_grid(W)), 0, (const Col8*)part.get(), S, W, (const Acc9*)C.get(), out);
   return ZK_OK;
 }
 
