@@ -345,7 +345,9 @@ def run_sharded(args, zk, dims, batch, rank, world, dist):
     from zkdl_amd.shard import Shard, dist_allgather, prove_sharded, prove_sharded_stream
     import torch
     per = batch // world
-    shard = Shard(Workload(zk, dims, batch, seed=0, rows=(rank * per, (rank + 1) * per)), rank, world)
+    ft = args.full_tables if (args.msm == "pippenger" and not args.msm_window and args.workload.startswith(("mlp18m", "tiny"))) else 0   # digit tables, as the headline
+    shard = Shard(Workload(zk, dims, batch, seed=0, rows=(rank * per, (rank + 1) * per), full_tables=ft), rank, world)
+    zk.set_flag("derive_rounds", 0 if args.no_derive else 1)
 
     def challenges(step):
         zk.seed(0xFACE + step)
@@ -401,7 +403,7 @@ def run_sharded(args, zk, dims, batch, rank, world, dist):
                           "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
                           "dtype": "u32x8 (Fr) / u32x12 (Fp) limbs", "data": "synthetic",
                           "config": {"workload": args.workload, "dims": dims, "batch_total": batch, "rows_per_gpu": per,
-                                     "parallelism": "one proof sharded by batch rows; two all-gathers per proof (zkdl_amd/shard.py)", "proofs_in_flight": 1 if args.no_pipeline else 3},
+                                     "parallelism": "one proof sharded by batch rows; two all-gathers per proof (zkdl_amd/shard.py)", "proofs_in_flight": 1 if args.no_pipeline else 3, "full_table_window_bits": ft},
                           "transcript_values": [int(fr.shape[0]), int(aff.shape[0])],
                           "transcript_sha256": __import__("hashlib").sha256(fr.tobytes() + aff.tobytes() + inf.tobytes()).hexdigest()}) + "\n")
         OUT.flush()

@@ -280,6 +280,10 @@ int zk_transcript_serialize(zk_transcript* tr, void* buf_h, size_t cap, size_t* 
  * waits for the sealed phase first; work that consumes out8_d must be ordered on zk_transcript_stream(tr).
  * Without worker lanes this degrades to flush + digest_dev on the main stream (same values). */
 int zk_transcript_seal(zk_transcript* tr, uint64_t* out8_d);
+/* Read a SEALED transcript (Fr values; G1 values affine-canonical + infinity flags) waiting for nothing but that transcript's own sealed phase: the other
+ * proofs in flight keep running (zk_transcript_read / read_affine synchronise the whole context).  The transcript stays sealed. */
+int zk_transcript_sizes(const zk_transcript* tr, size_t* n_fr, size_t* n_g1);   /* counts without flushing or waiting (zk_transcript_counts does both) */
+int zk_transcript_read_sealed(zk_transcript* tr, zk_fr* fr_h, size_t fr_cap, zk_g1a* g1_h, uint8_t* inf_h, size_t g1_cap);
 /* Two proofs submitted together: same values as zk_transcript_seal(a, ..) followed by zk_transcript_seal(b, ..), but the recorded
  * Fr work of both runs as ONE set of batched launches (each launch carries the jobs of both proofs), then each proof's G1 phase
  * goes to its own G1 stream.  No reference counterpart (the reference proves one batch at a time, synchronously); throughput

@@ -34,7 +34,7 @@ zk_set_msm_window zk_set_flag zk_gens_create zk_gens_destroy zk_gens_size zk_gen
 zk_fc_out zk_fc_com_size zk_fc_weights zk_fc_com zk_fc_load_input zk_fc_forward zk_fc_prove zk_relu_create
 zk_relu_destroy zk_relu_forward zk_relu_sign zk_relu_mag_bin zk_relu_rem_bin zk_relu_prove zk_transcript_create
 zk_transcript_destroy zk_transcript_reset zk_transcript_flush zk_transcript_counts zk_transcript_read zk_transcript_read_affine
-zk_transcript_digest zk_transcript_digest_dev zk_transcript_serialize zk_transcript_seal zk_transcript_seal_pair zk_transcript_stream
+zk_transcript_digest zk_transcript_digest_dev zk_transcript_serialize zk_transcript_seal zk_transcript_sizes zk_transcript_read_sealed zk_transcript_seal_pair zk_transcript_stream
 zk_verify_fc zk_verify_relu zk_verify_open zk_fs_derive zk_sha256 zk_fc_prove_fs zk_relu_prove_fs zk_leaky_prove_fs zk_fs_round_challenges zk_relu_set_activation zk_leaky_prove zk_verify_leaky zk_act_open zk_act_open_fs zk_act_commit zk_verify_act_open zk_dist_unique_id zk_dist_init zk_dist_world_size zk_dist_sum_rows zk_dist_allreduce_u64
 zk_dist_lanes_to_fr zk_dist_destroy zk_gens_prepare_full zk_field_selftest""".split()
 
@@ -686,6 +686,22 @@ class Transcript:
     def seal(self, out8_ptr=None):
         """Finish the proof on the G1 stream without making the main stream wait (zk_transcript_seal)."""
         self.zk._chk(self.zk.lib.zk_transcript_seal(self.h, _vp(out8_ptr) if out8_ptr else None))
+
+    def read_sealed(self):
+        """(Fr, affine G1, infinity flags) of a SEALED transcript, waiting for that transcript only (zk_transcript_read_sealed)."""
+        a, b = _sz(), _sz()
+        self.zk._chk(self.zk.lib.zk_transcript_sizes(self.h, ctypes.byref(a), ctypes.byref(b)))
+        nf, ng = a.value, b.value
+        fr = np.zeros((max(nf, 1), 8), dtype=np.uint32)
+        aff = np.zeros((max(ng, 1), 24), dtype=np.uint32)
+        inf = np.zeros(max(ng, 1), dtype=np.uint8)
+        self.zk._chk(self.zk.lib.zk_transcript_read_sealed(self.h, _hp(fr), _sz(fr.shape[0]), _hp(aff), _hp(inf), _sz(aff.shape[0])))
+        return fr[:nf], aff[:ng], inf[:ng]
+
+    def serialize_sealed(self):
+        """zk_transcript_serialize's bytes for a SEALED transcript, without a context-wide wait (read_sealed + the on-disk framing)."""
+        fr, aff, inf = self.read_sealed()
+        return b"ZKDLTR01" + int(fr.shape[0]).to_bytes(8, "little") + int(aff.shape[0]).to_bytes(8, "little") + fr.tobytes() + aff.tobytes() + inf.tobytes()
 
     def seal_pair(self, other, out8_ptr=None, other_out8_ptr=None):
         """This proof and `other` submitted together: one zipped Fr phase, two G1 phases (zk_transcript_seal_pair)."""

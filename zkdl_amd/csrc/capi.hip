@@ -283,6 +283,7 @@ int zk_ctx_destroy(zk_ctx* ctx) {
     for (auto e : evs) (void)hipEventDestroy(e);
   (void)hipHostFree(ctx->stage);
   ctx->pool_destroy();
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   (void)hipStreamDestroy(ctx->main_stream);
   delete ctx;
   return ZK_OK;
@@ -893,6 +894,13 @@ int zk_transcript_seal_pair(zk_transcript* a, uint64_t* a_out8_d, zk_transcript*
   return a->seal_pair(b, a_out8_d, b_out8_d);
 }
 void* zk_transcript_stream(zk_transcript* tr) { return tr ? (void*)(tr->sealed_stream ? tr->sealed_stream : tr->ctx->main_stream) : nullptr; }
+// the numbers of values appended so far: host-side counters, known when a prove call returns (no flush, no wait)
+int zk_transcript_sizes(const zk_transcript* tr, size_t* n_fr, size_t* n_g1) {
+  if (!tr) return ZK_ERR_ARG;
+  if (n_fr) *n_fr = tr->n_fr;
+  if (n_g1) *n_g1 = tr->n_g1;
+  return ZK_OK;
+}
 int zk_transcript_counts(zk_transcript* tr, size_t* n_fr, size_t* n_g1) {
   if (!tr) return ZK_ERR_ARG;
   tr->ctx->join_lanes();
@@ -911,6 +919,37 @@ int zk_transcript_read(zk_transcript* tr, zk_fr* fr_h, size_t fr_cap, zk_g1j* g1
   if (tr->n_fr) ZK_TRY(zk_memcpy_d2h(ctx, fr_h, tr->fr_d, tr->n_fr * sizeof(Fr)));
   if (tr->n_g1) ZK_TRY(zk_memcpy_d2h(ctx, g1_h, tr->g1_d, tr->n_g1 * sizeof(G1J)));
   return zk_ctx_sync(ctx);
+}
+// A SEALED transcript read without synchronising anything else: the host waits for this transcript's own G1 phase (which waited for its Fr phase), and
+// the values travel on a private copy stream.  zk_transcript_read / read_affine join every worker stream and synchronise the context -- with several
+// proofs in flight that is a wait for ALL of them (zkdl_amd/shard.py's software pipeline gained nothing from it).  G1 values are already canonical
+// (x, y, Z = ONE; infinity {0, ONE, 0}) behind a sealed phase: the affine form is their first two coordinates.
+int zk_transcript_read_sealed(zk_transcript* tr, zk_fr* fr_h, size_t fr_cap, zk_g1a* g1_h, uint8_t* inf_h, size_t g1_cap) {
+  if (!tr) return ZK_ERR_ARG;
+  zk_ctx* ctx = tr->ctx;
+  (void)hipSetDevice(ctx->device);
+  if (fr_cap < tr->n_fr || g1_cap < tr->n_g1) return ctx->fail(ZK_ERR_ARG, "transcript buffers too small");
+  if ((tr->n_fr && !fr_h) || (tr->n_g1 && (!g1_h || !inf_h))) return ctx->fail(ZK_ERR_ARG, "zk_transcript_read_sealed: null buffer");
+  if (!tr->sealed || !tr->sealed_ev || ctx->msm_mode != ZK_MSM_PIPPENGER) {   // not sealed (or sealed synchronously): the ordinary reads
+    ZK_TRY(zk_transcript_read(tr, fr_h, fr_cap, nullptr, 0 * g1_cap));
+    return tr->n_g1 ? zk_transcript_read_affine(tr, g1_h, inf_h, g1_cap) : ZK_OK;
+  }
+  if (tr->g1_deferred) ZK_TRY(ctx->flush_g1_pending());   // its G1 phase was still waiting for partners
+  ZK_HIP(ctx, hipEventSynchronize(tr->sealed_ev));
+  if (!ctx->copy_stream) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  std::vector<G1J> jac(tr->n_g1);
+  if (tr->n_fr) ZK_HIP(ctx, hipMemcpyAsync(fr_h, tr->fr_d, tr->n_fr * sizeof(Fr), hipMemcpyDeviceToHost, ctx->copy_stream));
+  if (tr->n_g1) ZK_HIP(ctx, hipMemcpyAsync(jac.data(), tr->g1_d, tr->n_g1 * sizeof(G1J), hipMemcpyDeviceToHost, ctx->copy_stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+  for (size_t i = 0; i < tr->n_g1; i++) {
+    const bool inf = l_is_zero(jac[i].z);
+    G1A a;
+    a.x = inf ? fp_zero() : jac[i].x;
+    a.y = inf ? fp_zero() : jac[i].y;
+    memcpy(&g1_h[i], &a, sizeof a);
+    inf_h[i] = inf ? 1 : 0;
+  }
+  return ZK_OK;
 }
 int zk_transcript_read_affine(zk_transcript* tr, zk_g1a* g1_h, uint8_t* inf_h, size_t cap) {
   if (!tr) return ZK_ERR_ARG;

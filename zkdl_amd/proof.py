@@ -481,7 +481,7 @@ def prove_with_activation_commitments_stream(zk, dims, batch, gens, fcs, relus, 
                 t.seal()
             j = k - 1
             if 0 <= j < count:
-                aff, inf = trsA[j % inflight].read_affine()
+                _, aff, inf = trsA[j % inflight].read_sealed()
                 com[j] = (aff, inf)
                 aseed = act_seed_from_points(seed, dims, batch, aff, inf)
                 t = trsB[j % inflight]
@@ -497,7 +497,7 @@ def prove_with_activation_commitments_stream(zk, dims, batch, gens, fcs, relus, 
             j = k - 2
             if 0 <= j < count:
                 aff, inf = com.pop(j)
-                yield aff, inf, trsB[j % inflight].serialize()
+                yield aff, inf, trsB[j % inflight].serialize_sealed()
     finally:
         for t in trsA + trsB:
             t.close()

@@ -100,7 +100,7 @@ class Shard:
         """The host side of phase 1: ONE read of the sealed transcript (waits for that transcript only).  keep_on_device (a single rank: nothing
         crosses a process boundary): the contracted vectors stay where they are."""
         out, relu_lens_seen = state
-        fr, _ = tr.read()
+        fr, _, _ = tr.read_sealed()
         off = 0
         it = iter(relu_lens_seen)
         for part in out:
@@ -157,8 +157,7 @@ class Shard:
             return {}
         sh = self.wl.shapes
         chal_fc = self._chal_fc
-        fr, _ = tr.read()
-        aff, inf = tr.read_affine()
+        fr, aff, inf = tr.read_sealed()
         out, of, og = {}, 0, 0
         for c in mine:
             s = sh[chal_fc[c]]
