@@ -930,12 +930,19 @@ int zk_transcript_read_sealed(zk_transcript* tr, zk_fr* fr_h, size_t fr_cap, zk_
   (void)hipSetDevice(ctx->device);
   if (fr_cap < tr->n_fr || g1_cap < tr->n_g1) return ctx->fail(ZK_ERR_ARG, "transcript buffers too small");
   if ((tr->n_fr && !fr_h) || (tr->n_g1 && (!g1_h || !inf_h))) return ctx->fail(ZK_ERR_ARG, "zk_transcript_read_sealed: null buffer");
-  if (!tr->sealed || !tr->sealed_ev || ctx->msm_mode != ZK_MSM_PIPPENGER) {   // not sealed (or sealed synchronously): the ordinary reads
-    ZK_TRY(zk_transcript_read(tr, fr_h, fr_cap, nullptr, 0 * g1_cap));
+  if (ctx->msm_mode != ZK_MSM_PIPPENGER) {   // the literal back end leaves Jacobian representatives: the ordinary reads (they normalise)
+    std::vector<zk_g1j> scratch(tr->n_g1 ? tr->n_g1 : 1);
+    ZK_TRY(zk_transcript_read(tr, fr_h, fr_cap, scratch.data(), scratch.size()));
     return tr->n_g1 ? zk_transcript_read_affine(tr, g1_h, inf_h, g1_cap) : ZK_OK;
   }
-  if (tr->g1_deferred) ZK_TRY(ctx->flush_g1_pending());   // its G1 phase was still waiting for partners
-  ZK_HIP(ctx, hipEventSynchronize(tr->sealed_ev));
+  if (tr->sealed && tr->g1_deferred) ZK_TRY(ctx->flush_g1_pending());   // its G1 phase was still waiting for partners
+  if (tr->sealed && tr->sealed_ev) {
+    ZK_HIP(ctx, hipEventSynchronize(tr->sealed_ev));
+  } else {   // not sealed, or sealed synchronously (no G1 stream): finish it the ordinary way, then the same copies
+    ctx->join_lanes();
+    ZK_TRY(tr->flush());
+    ZK_TRY(zk_ctx_sync(ctx));
+  }
   if (!ctx->copy_stream) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
   std::vector<G1J> jac(tr->n_g1);
   if (tr->n_fr) ZK_HIP(ctx, hipMemcpyAsync(fr_h, tr->fr_d, tr->n_fr * sizeof(Fr), hipMemcpyDeviceToHost, ctx->copy_stream));
