@@ -158,6 +158,9 @@ int zk_set_msm_window(zk_ctx* ctx, uint32_t window_bits);   /* 0 = automatic; el
  *   "g1_streams"    (default 0 = all) how many of the context's G1 streams sealed proofs rotate over
  *   "early_g1"      a sealed proof's G1 phase starts behind the openings' scalar preparation (all it needs) instead of behind the whole
  *                   Fr phase; only the digest waits for the rest
+ *   "api_join"      (default 1) an immediate tensor call (zk_fr_*, zk_fc_forward, ...) first executes pending recordings and makes the main stream wait
+ *                   for every worker stream, so it may read what recorded work wrote; 0: it is launched behind earlier main-stream work only -- for
+ *                   callers whose operands do not come from recorded work still in flight (zkdl_amd/shard.py: the streamed phases)
  *   "weights_q16"   layers created while set keep an int16 copy of quantised weights (|w| < 2^15) for the
  *                   prover's two contractions of W and the integer forward pass */
 int zk_set_flag(zk_ctx* ctx, const char* name, int value);

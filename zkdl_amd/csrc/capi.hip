@@ -16,10 +16,14 @@ static_assert(sizeof(zk_g1a) == sizeof(G1A) && sizeof(zk_g1j) == sizeof(G1J), "P
 // every entry point except the lane-parallel provers first joins the worker lanes
 // every entry point except the prove calls first runs recorded-but-unexecuted layer work and joins the
 // worker lanes, so callers observe plain stream order
+// An immediate tensor call first SETTLES the context: pending recordings are executed and the main stream waits for every worker stream, so the call may
+// read whatever recorded work wrote.  With the flag "api_join" off (zk_set_flag) it does neither: the call is launched on the main stream behind
+// earlier main-stream work only -- for callers that know their operands do not come from recorded work still in flight (zkdl_amd/shard.py's streamed
+// phases: static tensors and host challenges in, buffers that only LATER recorded launches read out; those fork from the main stream, i.e. behind it).
 #define CHECK_CTX(ctx)                                  \
   if (!(ctx)) return ZK_ERR_ARG;                        \
   do {                                                  \
-    int _src = (ctx)->settle();                         \
+    int _src = (ctx)->api_join ? (ctx)->settle() : ZK_OK; \
     if (_src != ZK_OK) return _src;                     \
   } while (0)
 #define CHECK_CTX_NOJOIN(ctx) \
@@ -640,6 +644,7 @@ int zk_set_flag(zk_ctx* ctx, const char* name, int value) {
   else if (!strcmp(name, "derive_rounds")) ctx->derive_rounds = value != 0;
   else if (!strcmp(name, "pipeline_fr")) ctx->pipeline_fr = value != 0;
   else if (!strcmp(name, "early_g1")) ctx->early_g1 = value != 0;
+  else if (!strcmp(name, "api_join")) ctx->api_join = value != 0;
   else if (!strcmp(name, "full_tables")) ctx->full_tables = value != 0;
   else if (!strcmp(name, "g1_streams")) ctx->g1_active = value < 0 ? 0u : (uint32_t)value;
   else if (!strcmp(name, "g1_mask")) ctx->g1_masked = value != 0;

@@ -290,6 +290,10 @@ def prove_sharded_stream(shard, chals, allgather=None, inflight=3):
     chals = list(chals)
     K = len(chals)
     stA, stB, gathered = {}, {}, {}
+    # the phases' immediate calls (batch-side contractions, stand-ins) read static tensors, host challenges and what THIS loop has already read back, and
+    # write buffers that only later-recorded launches consume: they need main-stream order only, not a join of every worker stream ("api_join" off) --
+    # with the join each of them waited for the Fr phases of the proofs in flight, and the stream of proofs ran one proof at a time
+    shard.zk.set_flag("api_join", 0)
     try:
         for k in range(K + 2):
             if k < K:
@@ -305,6 +309,7 @@ def prove_sharded_stream(shard, chals, allgather=None, inflight=3):
                     owned.update(part)
                 yield shard.assemble(chals[j], gathered.pop(j), owned)
     finally:
+        shard.zk.set_flag("api_join", 1)
         for t in trsA + trsB:
             t.close()
 
