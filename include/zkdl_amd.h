@@ -355,8 +355,10 @@ int zk_act_open(zk_ctx* ctx, zk_gens* gens, const zk_fr* z_d, const zk_fr* a_d, 
                 zk_transcript* tr);
 /* Commitment::commit (the intended row MSM, as zk_commit) deferred into a transcript: appends the tn / n_gens points to tr's G1 list; the MSMs join the
  * transcript's batch (digit tables when present), so a sealed transcript computes them under other proofs' work.  Used for the per-input activation
- * commitments com(Z_i), com(A_i) (zkdl_amd/proof.py: prove_with_activation_commitments_stream). */
-int zk_act_commit(zk_ctx* ctx, zk_gens* gens, const zk_fr* t_d, uint32_t tn, zk_transcript* tr);
+ * commitments com(Z_i), com(A_i) (zkdl_amd/proof.py: prove_with_activation_commitments_stream).  max_bits: 0 (full width), or a bound on the bit length of
+ * the centred values min(v, r - v): only the windows such scalars can touch are walked; the device checks the bound, and zk_ctx_sync returns ZK_ERR_RANGE if
+ * a scalar was longer (zkReLU's inputs are < 2^47 in magnitude by zk_relu_forward's own range check, its outputs < 2^32). */
+int zk_act_commit(zk_ctx* ctx, zk_gens* gens, const zk_fr* t_d, uint32_t tn, uint32_t max_bits, zk_transcript* tr);
 /* The same with the reduction's challenges bound to the prover's messages (the sound mode of the layer proofs, zk_*_prove_fs): alpha =
  * zk_fs_derive(seed32, layer, 2, 0, 1) and every ROUND challenge -- hence the opening point r' -- is the hash chain of zk_fs_round_challenges with
  * kind = 2, which = 0 over the reduction's own round messages, computed on the device.  seed32 must absorb everything alpha may depend on: the

@@ -254,6 +254,24 @@ def test_activation_commitments_inside_the_pipeline(zk, oracle, dims, batch, tab
         og += w.n
     assert og == aff.shape[0]
     tr.close()
+    # with a stated bound on the scalars (activations are < 2^47 in magnitude) only their low windows are walked: same points ...
+    tr = Transcript(zk)
+    for i in range(len(dims) - 2):
+        zk.act_commit(st["gens"][i], st["Z"][i], tr, 48)
+        zk.act_commit(st["gens"][i], st["A"][i], tr, 48)
+    aff48, inf48 = tr.read_affine()
+    assert np.array_equal(aff48, aff) and np.array_equal(inf48, inf)
+    zk.sync()
+    # ... and a bound the tensor violates is caught on the device and reported by the next sync, not trusted
+    from zkdl_amd.capi import ZkError
+    tr.reset()
+    zk.act_commit(st["gens"][0], st["Z"][0], tr, 3)
+    tr.flush()
+    with pytest.raises(ZkError) as err:
+        zk.sync()
+    assert err.value.code == 5            # ZK_ERR_RANGE
+    zk.sync()                             # reported once
+    tr.close()
     # the streamed prover
     got = list(prove_with_activation_commitments_stream(zk, dims, batch, st["gens"], st["fcs"], st["relus"], st["X"], st["Z"], st["A"], st["Yhat"], seed, 5))
     assert len(got) == 5

@@ -524,9 +524,10 @@ class Zk:
             raise ShapeError(ZK_ERR_SHAPE, "Incompatible dimensions")
         self._chk(self.lib.zk_act_open(self.ctx, gens.h, _vp(z.ptr), _vp(a.ptr), _u32(z.n), _hp(_fr_host(pts)), _hp(_fr_host(alpha, 1)), _hp(fold), tr.h))
 
-    def act_commit(self, gens, t, tr):
-        """zk_act_commit: the row-wise commitment of tensor t over gens, deferred into tr (t.n / gens.n points appended to its G1 list)."""
-        self._chk(self.lib.zk_act_commit(self.ctx, gens.h, _vp(t.ptr), _u32(t.n), tr.h))
+    def act_commit(self, gens, t, tr, max_bits=0):
+        """zk_act_commit: the row-wise commitment of tensor t over gens, deferred into tr (t.n / gens.n points appended to its G1 list).
+        max_bits: a bound on the centred values' bit length (0 = full width); checked on the device (ZK_ERR_RANGE from the next sync)."""
+        self._chk(self.lib.zk_act_commit(self.ctx, gens.h, _vp(t.ptr), _u32(t.n), _u32(max_bits), tr.h))
 
     def act_open_fs(self, gens, z, a, pts, seed32, layer, tr):
         """zk_act_open_fs: the same with alpha and the reduction's round challenges hashed from seed32 and the reduction's own round messages."""

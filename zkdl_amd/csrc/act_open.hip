@@ -190,13 +190,16 @@ int zk_act_open(zk_ctx* ctx, zk_gens* gens, const zk_fr* z_d, const zk_fr* a_d, 
 // tn / n_gens commitment points are appended to tr's G1 list and their MSMs join the transcript's batch -- on the digit tables when the generator set
 // has them (a zero digit costs nothing there, so short scalars such as activations pay for their non-zero windows only), and a sealed transcript runs them
 // under other proofs' work.  This is what makes the activation commitments part of the proving pipeline instead of a synchronous setup call per tensor.
-int zk_act_commit(zk_ctx* ctx, zk_gens* gens, const zk_fr* t_d, uint32_t tn, zk_transcript* tr) {
+// max_bits: 0, or the caller's bound on the bit length of the CENTRED values (min(v, r - v)): only the windows such scalars can touch are walked -- a 48-bit
+// activation is 5 of 22 twelve-bit windows; a longer scalar raises the context's range flag (zk_ctx_sync returns ZK_ERR_RANGE).
+int zk_act_commit(zk_ctx* ctx, zk_gens* gens, const zk_fr* t_d, uint32_t tn, uint32_t max_bits, zk_transcript* tr) {
   if (!ctx) return ZK_ERR_ARG;
   (void)hipSetDevice(ctx->device);
   if (!gens || !t_d || !tr) return ctx->fail(ZK_ERR_ARG, "zk_act_commit: null argument");
   if (((uintptr_t)t_d) & 15u) return ctx->fail(ZK_ERR_ARG, "misaligned device pointer");
   const uint32_t n = gens->n;
   if (n == 0 || tn == 0 || tn % n) return ctx->fail(ZK_ERR_SHAPE, "Incompatible dimensions");   // commitment.cu:31
+  if (max_bits > 254) return ctx->fail(ZK_ERR_ARG, "zk_act_commit: max_bits 0 .. 254");
   const uint32_t m = tn / n;
   ActGuard guard(ctx, tr);
   auto body = [&]() -> int {
@@ -207,7 +210,7 @@ int zk_act_commit(zk_ctx* ctx, zk_gens* gens, const zk_fr* t_d, uint32_t tn, zk_
     if (recording.rc != ZK_OK) return recording.rc;
     rec_split(ctx, REC_GROUP_FC_OPEN, /*early=*/true);   // scalar preparation only: the G1 phase may start behind it
     LaneScope lane(ctx, recording.on ? ~0u : 0u);
-    return msm_enqueue(ctx, gens, reinterpret_cast<const Fr*>(t_d), m, /*do_unmont=*/true, /*probe_bits=*/false, slot, &tr->queue);
+    return msm_enqueue(ctx, gens, reinterpret_cast<const Fr*>(t_d), m, /*do_unmont=*/true, /*probe_bits=*/false, slot, &tr->queue, nullptr, nullptr, max_bits);
   };
   return guard.finish(body());
 }

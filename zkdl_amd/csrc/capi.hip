@@ -244,6 +244,8 @@ int zk_ctx_create(int device, zk_ctx** out) {
     delete ctx;
     return ZK_ERR_ALLOC;
   }
+  if (hipHostMalloc((void**)&ctx->range_flag, 64, hipHostMallocDefault) == hipSuccess) *ctx->range_flag = 0;
+  else ctx->range_flag = nullptr;
   *out = ctx;
   return ZK_OK;
 }
@@ -287,6 +289,7 @@ int zk_ctx_destroy(zk_ctx* ctx) {
     for (auto e : evs) (void)hipEventDestroy(e);
   (void)hipHostFree(ctx->stage);
   ctx->pool_destroy();
+  if (ctx->range_flag) (void)hipHostFree(ctx->range_flag);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   (void)hipStreamDestroy(ctx->main_stream);
   delete ctx;
@@ -297,6 +300,10 @@ int zk_ctx_sync(zk_ctx* ctx) {
   ZK_TRY(ctx->flush_g1_pending());
   ctx->join_all();
   ZK_HIP(ctx, hipStreamSynchronize(ctx->main_stream));
+  if (ctx->range_flag && *(volatile uint32_t*)ctx->range_flag) {
+    *ctx->range_flag = 0;
+    return ctx->fail(ZK_ERR_RANGE, "a scalar was longer than the bound its caller stated (zk_act_commit max_bits): the commitments of that batch are wrong");
+  }
   return ZK_OK;
 }
 const char* zk_last_error(const zk_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }

@@ -168,6 +168,7 @@ struct zk_ctx {
   std::vector<Lane> tail_lanes;
   uint32_t next_tail = 0;
   hipStream_t main_stream = nullptr;
+  uint32_t* range_flag = nullptr;      // pinned host word a device-side check raises (msm.hip: k_bits_guard); zk_ctx_sync reports and clears it
   bool api_join = true;                // immediate tensor calls settle the context first (capi.hip: CHECK_CTX); off: main-stream order only
   hipStream_t copy_stream = nullptr;   // zk_transcript_read_sealed: device-to-host copies that wait for nothing but their own transcript
   hipEvent_t fork_ev = nullptr;

@@ -26,6 +26,7 @@ struct MsmJobHost {  // one pending MSM: *out = sum_j mags[j] * base_j over tabl
   G1J* out;
   uint32_t W;
   const G1FullTable* F = nullptr;  // not null: the job runs on the bucket-free path (msm.hip: k_msmf_*)
+  uint32_t Wuse = 0;                  // bucket-free path: windows to walk (0 = all W): scalars with a stated bound (zk_act_commit)
   uint8_t pat_r = 0xff, pat_par = 0;  // scalars known to vanish outside { i : ((i >> pat_r) & 1) == pat_par } (0xff: dense) -- T0_r / T1_r of the flattened opening
 };
 struct DeriveJobHost {  // T_1 .. T_{k-1} of one me_open, derived from T_0 and the T0_j / T1_j behind the MSM batch (msm.hip)
@@ -133,8 +134,9 @@ void gens_destroy(zk_gens* g);
 int gens_table(zk_ctx* ctx, zk_gens* g, uint32_t c, uint32_t W, const G1Table** out);
 int msm_batch_dev(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_unmont, bool probe_bits, G1J* out);
 // pattern (optional, q entries): (r << 1) | parity per row, 0x1fe = dense -- see MsmJobHost::pat_r
+// bits_bound (optional): the caller's bound on the scalars' centred bit length; fewer windows are walked, and the device raises the context's range flag if a scalar is longer
 int msm_enqueue(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_unmont, bool probe_bits, G1J* out, MsmQueue* queue, const uint32_t* out_idx = nullptr,
-                const uint16_t* pattern = nullptr);
+                const uint16_t* pattern = nullptr, uint32_t bits_bound = 0);
 int gens_prepare_full(zk_ctx* ctx, zk_gens* g, uint32_t c);
 int msm_run_derives(zk_ctx* ctx, const std::vector<DeriveJobHost>& derives);
 int msm_flush(zk_ctx* ctx, MsmQueue* queue);

@@ -142,6 +142,14 @@ __device__ __forceinline__ void k_scalar_prep(uint32_t zk_nblk, const Fr* __rest
   if ((threadIdx.x & 63u) == 0 && mx) atomicMax(maxbits, mx);
 }
 
+// a caller-stated bound on the scalars' bit length (zk_act_commit) is checked, not trusted: a longer scalar raises the context's sticky range flag (pinned
+// host word), which zk_ctx_sync turns into ZK_ERR_RANGE
+__device__ __forceinline__ void k_bits_guard(uint32_t zk_nblk, const uint32_t* __restrict__ maxbits, uint32_t bound, uint32_t* __restrict__ flag) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && *maxbits > bound) {
+    __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // K = sum_{w < W} 2^(c*w + c - 1): every c-bit window of mag + K equals (signed digit + 2^(c-1)).
 struct RecodeK {
   uint32_t v[9];
@@ -641,6 +649,7 @@ struct FullJob {
   uint32_t n, W, nnz;
   uint32_t pat_r, pat_par;
   uint64_t part_off;
+  uint32_t Wuse;   // windows 0 .. Wuse-1 are walked (scalars known to be short: zk_act_commit); the table's row stride stays W
 };
 static constexpr uint32_t FT_SEG = 64;  // points put into affine form per shared inversion
 #ifndef ZK_FT_SUBS
@@ -705,7 +714,7 @@ template <bool INL, int AHEAD>
 __device__ __forceinline__ void msmf_accum_body(const FullJob* __restrict__ jobs, uint32_t c, const RecodeK& K, G1X* __restrict__ partial) {
   const FullJob job = jobs[blockIdx.y];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t items = (uint64_t)job.nnz * job.W;
+  const uint64_t items = (uint64_t)job.nnz * job.Wuse;
   if ((uint64_t)t * (MSM_CHUNK * FT_SUBS) >= items) return;
   const uint32_t half_log = c - 1;
   const ZK_GLOBAL G1AE* tab = (const ZK_GLOBAL G1AE*)job.tab;
@@ -719,13 +728,13 @@ __device__ __forceinline__ void msmf_accum_body(const FullJob* __restrict__ jobs
   const uint64_t e0 = ((uint64_t)t * FT_SUBS + sub) * MSM_CHUNK;
   if (e0 >= items) break;
   const uint64_t e1 = e0 + MSM_CHUNK < items ? e0 + MSM_CHUNK : items;
-  const uint32_t pt0 = (uint32_t)(e0 / job.W), w0 = (uint32_t)(e0 - (uint64_t)pt0 * job.W);
+  const uint32_t pt0 = (uint32_t)(e0 / job.Wuse), w0 = (uint32_t)(e0 - (uint64_t)pt0 * job.Wuse);
   // pass 1 (integer work only): the chunk's table offsets; bit 63 = negate, ~0 = nothing to add (digit 0, infinite base).  A chunk of 16
   // point-major items touches at most two points when a point has >= 16 windows (every width up to 16 bits): both scalars are requested at
   // once -- one wait instead of a dependent load + wait per item
   uint64_t offs[MSM_CHUNK];
-  if (job.W >= MSM_CHUNK) {
-    const uint32_t split = job.W - w0;  // items [0, split) belong to point pt0, the rest to pt0 + 1
+  if (job.Wuse >= MSM_CHUNK) {
+    const uint32_t split = job.Wuse - w0;  // items [0, split) belong to point pt0, the rest to pt0 + 1
     const bool two = e0 + split < e1;
     const uint32_t iA = pat_index(pt0, job.pat_r, job.pat_par), iB = two ? pat_index(pt0 + 1, job.pat_r, job.pat_par) : iA;
     const uint8_t fA = inf[iA], fB = inf[iB];
@@ -777,7 +786,7 @@ __device__ __forceinline__ void msmf_accum_body(const FullJob* __restrict__ jobs
           const uint32_t d = recode_digit(rc, c, w, neg);
           if (d) o = (((((uint64_t)i * job.W + w)) << half_log) + (d - 1)) | (neg ? (1ull << 63) : 0ull);
         }
-        if (++w == job.W) {
+        if (++w == job.Wuse) {
           w = 0;
           pt++;
           fresh = true;
@@ -833,7 +842,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 __global__ void __launch_bounds__(256) k_msmf_reduce(const FullJob* __restrict__ jobs, const G1X* __restrict__ partial) {
   __shared__ G1X sm[4];
   const FullJob job = jobs[blockIdx.x];
-  const uint64_t items = (uint64_t)job.nnz * job.W;
+  const uint64_t items = (uint64_t)job.nnz * job.Wuse;
   const uint32_t np = (uint32_t)((items + MSM_CHUNK * FT_SUBS - 1) / (MSM_CHUNK * FT_SUBS));
   G1X acc = g1x_zero();
   for (uint32_t p = threadIdx.x; p < np; p += 256) acc = g1x_add(acc, partial[job.part_off + p]);
@@ -898,7 +907,8 @@ static int msm_run_full_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs) 
     j.pat_par = h.pat_par;
     j.nnz = h.pat_r == 0xff ? j.n : j.n / 2;
     j.part_off = parts;
-    const uint64_t items = (uint64_t)j.nnz * W;
+    j.Wuse = h.Wuse && h.Wuse < W ? h.Wuse : W;
+    const uint64_t items = (uint64_t)j.nnz * j.Wuse;
     const uint32_t lanes = (uint32_t)((items + MSM_CHUNK * FT_SUBS - 1) / (MSM_CHUNK * FT_SUBS));
     parts += lanes;
     items_all += items;
@@ -1013,7 +1023,7 @@ static int msm_run_bucket_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs
 
 // prepare q scalar rows over the generator set g and append them as jobs (out[i] receives MSM i)
 int msm_enqueue(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_unmont, bool probe_bits, G1J* out, MsmQueue* queue, const uint32_t* out_idx,
-                const uint16_t* pattern) {
+                const uint16_t* pattern, uint32_t bits_bound) {
   const uint32_t n = g->n;
   if (q == 0) return ZK_OK;
   if (ctx->rec && !ctx->rec->chains.empty() && !ctx->rec->chains.back().early) queue->late_inputs = true;
@@ -1027,10 +1037,15 @@ int msm_enqueue(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_
   if (probe_bits) {  // setup-time paths only (commit): one host round trip buys 10x fewer windows
     ZK_TRY(dev_to_host(ctx, &bits, maxbits.get(), 4));
   }
+  if (bits_bound && bits_bound < 254 && !probe_bits) {  // the caller states a bound (no host round trip): use it, and have the device check it
+    bits = bits_bound;
+    if (ctx->range_flag) ZK_LAUNCHB(ctx, "msm_scalar_prep", 8, 64, k_bits_guard, dim3(1), 0, (const uint32_t*)maxbits.get(), bits_bound, ctx->range_flag);
+  }
   if (!probe_bits && ctx->full_tables && g->full.pts && !ctx->msm_window) {  // full-width scalars over a prepared generator set: the bucket-free path
     for (uint32_t i = 0; i < q; i++) {
       MsmJobHost h{nullptr, mags.get() + (uint64_t)i * n, out + (out_idx ? out_idx[i] : i), g->full.W};
       h.F = &g->full;
+      h.Wuse = msm_num_windows(bits, g->full.c);   // short scalars: their low windows only
       if (pattern && pattern[i] != 0x1fe && n >= 2) {
         h.pat_r = (uint8_t)(pattern[i] >> 1);
         h.pat_par = (uint8_t)(pattern[i] & 1u);

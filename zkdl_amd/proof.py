@@ -457,13 +457,14 @@ def act_seed_from_points(seed, dims, batch, aff, inf):
     return sha256(b"".join(parts))
 
 
-def prove_with_activation_commitments_stream(zk, dims, batch, gens, fcs, relus, X, Z, A, Yhat, seed, count, inflight=3):
+def prove_with_activation_commitments_stream(zk, dims, batch, gens, fcs, relus, X, Z, A, Yhat, seed, count, inflight=3, max_bits=48):
     """`count` proofs of one statement, each WITH its activation commitments, software-pipelined in two sealed stages per proof:
         A: com(Z_i), com(A_i) of every hidden layer as deferred row MSMs (zk_act_commit) on their own transcript -- read back when they are done, because
            the openings' challenges must depend on them (act_statement_seed);
         B: the layer proofs (statement-derived challenges) and the activation openings (challenges from the seed that absorbed stage A's points).
     While proof k's stage A is read, proof k + 1's stage A and proof k - 1's stage B are on the device: the commitments cost their MSM work
-    (7 M short-scalar products per 18M / batch-256 proof) but no idle time.  Yields (commitment points affine, their infinity flags, serialised stage-B proof)."""
+    (7 M short-scalar products per 18M / batch-256 proof) but no idle time.  max_bits: the bound passed to zk_act_commit (zkReLU's inputs are < 2^47 in
+    magnitude -- zk_relu_forward refuses anything else -- and its outputs < 2^32; 0 = full width).  Yields (commitment points affine, their infinity flags, serialised stage-B proof)."""
     from .capi import Transcript
     chal = fs_challenges(seed, dims, batch)
     L = len(dims) - 1
@@ -476,8 +477,8 @@ def prove_with_activation_commitments_stream(zk, dims, batch, gens, fcs, relus, 
                 t = trsA[k % inflight]
                 t.reset()
                 for i in range(L - 1):
-                    zk.act_commit(gens[i], Z[i], t)
-                    zk.act_commit(gens[i], A[i], t)
+                    zk.act_commit(gens[i], Z[i], t, max_bits)
+                    zk.act_commit(gens[i], A[i], t, max_bits)
                 t.seal()
             j = k - 1
             if 0 <= j < count:
