@@ -373,7 +373,7 @@ def run_sharded(args, zk, dims, batch, rank, world, dist):
         if world > 1:
             dist.barrier()
 
-    # software-pipelined: three proofs in flight, every phase a sealed transcript (zkdl_amd/shard.py: prove_sharded_stream); --no-pipeline: one proof
+    # software-pipelined: five proofs in flight, every phase a sealed transcript (zkdl_amd/shard.py: prove_sharded_stream); --no-pipeline: one proof
     # at a time, three host reads each
     stream_gather = None if world == 1 else dist_allgather
     if args.no_pipeline:
@@ -403,7 +403,7 @@ def run_sharded(args, zk, dims, batch, rank, world, dist):
                           "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
                           "dtype": "u32x8 (Fr) / u32x12 (Fp) limbs", "data": "synthetic",
                           "config": {"workload": args.workload, "dims": dims, "batch_total": batch, "rows_per_gpu": per,
-                                     "parallelism": "one proof sharded by batch rows; two all-gathers per proof (zkdl_amd/shard.py)", "proofs_in_flight": 1 if args.no_pipeline else 3, "full_table_window_bits": ft},
+                                     "parallelism": "one proof sharded by batch rows; two all-gathers per proof (zkdl_amd/shard.py)", "proofs_in_flight": 1 if args.no_pipeline else 5, "full_table_window_bits": ft},
                           "transcript_values": [int(fr.shape[0]), int(aff.shape[0])],
                           "transcript_sha256": __import__("hashlib").sha256(fr.tobytes() + aff.tobytes() + inf.tobytes()).hexdigest()}) + "\n")
         OUT.flush()

@@ -65,7 +65,7 @@ def test_mlp18m_batch256_sharded_over_8(zk):
 
 @pytest.mark.parametrize("dims,batch", [([40, 24, 12], 8), ([64, 96, 48, 32], 16)])
 def test_pipelined_sharded_stream_equals_the_sequential_one(zk, dims, batch):
-    """prove_sharded_stream keeps three sharded proofs in flight (every phase a sealed transcript, one read per phase waits for that transcript
+    """prove_sharded_stream keeps five sharded proofs in flight (every phase a sealed transcript, one read per phase waits for that transcript
     only): each proof it yields is the single-GPU transcript of its own challenges, bit for bit, in order."""
     import bench
     from zkdl_amd.capi import Transcript

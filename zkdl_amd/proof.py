@@ -457,7 +457,7 @@ def act_seed_from_points(seed, dims, batch, aff, inf):
     return sha256(b"".join(parts))
 
 
-def prove_with_activation_commitments_stream(zk, dims, batch, gens, fcs, relus, X, Z, A, Yhat, seed, count, inflight=3, max_bits=48):
+def prove_with_activation_commitments_stream(zk, dims, batch, gens, fcs, relus, X, Z, A, Yhat, seed, count, depth=2, max_bits=48):
     """`count` proofs of one statement, each WITH its activation commitments, software-pipelined in two sealed stages per proof:
         A: com(Z_i), com(A_i) of every hidden layer as deferred row MSMs (zk_act_commit) on their own transcript -- read back when they are done, because
            the openings' challenges must depend on them (act_statement_seed);
@@ -468,11 +468,12 @@ def prove_with_activation_commitments_stream(zk, dims, batch, gens, fcs, relus, 
     from .capi import Transcript
     chal = fs_challenges(seed, dims, batch)
     L = len(dims) - 1
+    inflight = 2 * depth + 1          # `depth` proofs between a stage's submission and its read
     trsA = [Transcript(zk) for _ in range(inflight)]
     trsB = [Transcript(zk) for _ in range(inflight)]
     com = {}
     try:
-        for k in range(count + 2):
+        for k in range(count + 2 * depth):
             if k < count:
                 t = trsA[k % inflight]
                 t.reset()
@@ -480,7 +481,7 @@ def prove_with_activation_commitments_stream(zk, dims, batch, gens, fcs, relus, 
                     zk.act_commit(gens[i], Z[i], t, max_bits)
                     zk.act_commit(gens[i], A[i], t, max_bits)
                 t.seal()
-            j = k - 1
+            j = k - depth
             if 0 <= j < count:
                 _, aff, inf = trsA[j % inflight].read_sealed()
                 com[j] = (aff, inf)
@@ -495,7 +496,7 @@ def prove_with_activation_commitments_stream(zk, dims, batch, gens, fcs, relus, 
                         fcs[i].prove(A[i - 1] if i > 0 else X, Z[i], gens[i], ch[0], ch[1], ch[2], t)
                 prove_activation_openings(zk, dims, batch, gens, Z, A, chal, aseed, t)
                 t.seal()
-            j = k - 2
+            j = k - 2 * depth
             if 0 <= j < count:
                 aff, inf = com.pop(j)
                 yield aff, inf, trsB[j % inflight].serialize_sealed()

@@ -274,7 +274,7 @@ def prove_sharded(shards, chal, allgather=None):
     return sh.assemble(chal, gathered, owned)
 
 
-def prove_sharded_stream(shard, chals, allgather=None, inflight=3):
+def prove_sharded_stream(shard, chals, allgather=None, depth=2):
     """K sharded proofs, software-pipelined: while proof k's first phase is being read, proof k + 1's first phase and proof k - 1's second phase
     are already on the device (every phase is a SEALED transcript: a read waits for that transcript only), so the three host reads per proof
     no longer leave the GPU idle.  `shard`: this process's Shard; `allgather` as in prove_sharded (None: a single rank, payloads stay on the device).
@@ -285,6 +285,9 @@ def prove_sharded_stream(shard, chals, allgather=None, inflight=3):
         if shard.world != 1:
             raise ValueError("prove_sharded_stream without a collective is the one-rank form")
         allgather = lambda obj: [obj]
+    # `depth` proofs between a phase's submission and its read: 2 * depth + 1 proofs in flight (each phase on its own is latency-bound -- 2.5 and 3-4 ms
+    # for ~3 ms of chip work -- so the chip fills only when several overlap)
+    inflight = 2 * depth + 1
     trsA = [Transcript(shard.zk) for _ in range(inflight)]
     trsB = [Transcript(shard.zk) for _ in range(inflight)]
     chals = list(chals)
@@ -295,14 +298,14 @@ def prove_sharded_stream(shard, chals, allgather=None, inflight=3):
     # with the join each of them waited for the Fr phases of the proofs in flight, and the stream of proofs ran one proof at a time
     shard.zk.set_flag("api_join", 0)
     try:
-        for k in range(K + 2):
+        for k in range(K + 2 * depth):
             if k < K:
                 stA[k] = shard.local_enqueue(chals[k], trsA[k % inflight])
-            j = k - 1
+            j = k - depth
             if 0 <= j < K:
                 gathered[j] = allgather(shard.local_collect(stA.pop(j), trsA[j % inflight], keep_on_device=single))
                 stB[j] = shard.owner_enqueue(chals[j], gathered[j], trsB[j % inflight])
-            j = k - 2
+            j = k - 2 * depth
             if 0 <= j < K:
                 owned = {}
                 for part in allgather(shard.owner_collect(stB.pop(j), trsB[j % inflight])):
