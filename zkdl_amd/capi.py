@@ -93,7 +93,7 @@ def load_library():
 def _load_library():
     # ZKDL_AMD_LIB=<path>: another build of the SAME library (tools/ab_phases.sh points it at lib/variants/lib_exp.so, the -DZKDL_EXPERIMENTS build,
     # instead of swapping files); never the oracle, never a CPU fallback
-    path = os.environ.get("ZKDL_AMD_LIB") or LIB_PATH
+    path = os.environ.get("ZKDL_AMD_LIB") or LIB_PATH          # (empty = the shipping library)
     if path != LIB_PATH:
         if not os.path.exists(path):
             raise RuntimeError("ZKDL_AMD_LIB=%s does not exist" % path)
