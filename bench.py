@@ -685,7 +685,10 @@ def main():
 
     t_spin = time.perf_counter()
     n_spin = 0
-    while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
+    # ... and at least two rounds over the transcripts in flight: the pools must have seen every in-flight shape before the timed region (deep4096x64: a proof's
+    # bucket arrays are gigabytes, and a run that still grows the pools spends 100-400 ms per step in allocation calls on the host)
+    min_spin = 2 * len(wl.trs) if (pipelined and args.spinup_ms > 0) else 0
+    while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms or n_spin < min_spin:
         step(-100000 - n_spin, scratch_base)
         n_spin += 1
         if n_spin % 8 == 0:

@@ -18,13 +18,24 @@ def main():
     zk = Zk(0)
     zk.set_msm_mode(MSM_PIPPENGER)
     zk.seed(11)
-    n, q = 4096, 4096
+    n = int(sys.argv[sys.argv.index("--gens") + 1]) if "--gens" in sys.argv else 4096          # generators per MSM; rows = 2^24 / n
+    q = (1 << 24) // n
+    bits = int(sys.argv[sys.argv.index("--bits") + 1]) if "--bits" in sys.argv else 0             # 0: uniform below r; else uniform below 2^bits (an empty top window)
     gens = zk.gens(zk.g1_mul(zk.g1_fill(n, generator_jac()), zk.fr_random(n)))
-    full = zk.fr_random(n * q)
+    if bits:
+        import numpy as np
+        raw = np.random.default_rng(5).integers(0, 1 << 32, size=(n * q, 8), dtype=np.uint64).astype(np.uint32)
+        for limb in range(8):
+            keep = min(32, max(0, bits - 32 * limb))
+            raw[:, limb] &= np.uint32((1 << keep) - 1 if keep < 32 else 0xffffffff)
+        full = zk.upload(raw, 8)
+    else:
+        full = zk.fr_random(n * q)
     small = zk.fr_mont(zk.fr_random_int(n * q, 13))
     rows = []
     ref_full = ref_small = None
-    for c in [0] + list(range(6, 14)):          # zk_set_msm_window admits 2 .. 13 (the r03 sweep listed 14-16: those were 13, clamped)
+    widths = [int(x) for x in sys.argv[sys.argv.index("--windows") + 1].split(",")] if "--windows" in sys.argv else [0] + list(range(6, 14))
+    for c in widths:          # zk_set_msm_window admits 2 .. 13 (the r03 sweep listed 14-16: those were 13, clamped)
         zk.set_msm_window(c)
         rec = {"window": c}
         for name, fn in (("fullwidth_msm_batch", lambda: zk.msm_batch(gens, full)), ("quantised_commit", lambda: zk.commit(gens, small))):
@@ -35,6 +46,14 @@ def main():
             ms = zk.timer_stop_ms()
             rec[name + "_ms"] = ms
             rec[name + "_mops"] = n * q / ms / 1e3
+            if "--phases" in sys.argv and name.startswith("full"):   # the same call once more under the per-launch event profile (serialises nothing: one stream)
+                zk.prof_enable(True)
+                zk.prof_reset()
+                out = fn()
+                zk.sync()
+                rec["phases_ms"] = {k: round(v["ms"], 3) for k, v in zk.prof_read().items() if v["ms"] > 0.05}
+                zk.prof_enable(False)
+                print("      phases:", "  ".join("%s=%.2f" % kv for kv in sorted(rec["phases_ms"].items(), key=lambda kv: -kv[1])), flush=True)
             aff, inf = zk.g1_to_affine(out.view(0, 64))          # every width must give the same group elements
             key = (aff.tobytes(), inf.tobytes())
             if name.startswith("full"):
@@ -50,7 +69,7 @@ def main():
     # the bucket-free path: every signed digit of every window precomputed (zk_gens_prepare_full); same group elements
     zk.set_msm_window(0)
     table_rows = []
-    for c in (8, 10, 11, 12, 13):
+    for c in (() if "--no-tables" in sys.argv else (8, 10, 11, 12, 13)):
         g2 = zk.gens(gens.points())
         g2.prepare_full(c)
         zk.sync()

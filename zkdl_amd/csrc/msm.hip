@@ -477,7 +477,12 @@ __global__ void __launch_bounds__(64) k_msm_combine(const MsmJob* __restrict__ j
   const uint32_t B = 1u << (c - 1);
   const uint32_t q = blockIdx.y;
   const uint32_t sub = threadIdx.x % LPB;
-  const uint32_t b = blockIdx.x * (64u / LPB) + (threadIdx.x / LPB) + 1;
+  // Workgroups reach the XCDs (and the compute units inside one) round-robin in launch order, and the crowded buckets of every MSM -- the few magnitudes the
+  // partial top window can take, up to half of an MSM's points in ONE bucket -- sit in the same block of every job: with a block count that is a multiple of 8
+  // all the long chains of a batch landed on four compute units of one XCD (measured, 2^24 pairs at c = 11 / 12: 28-48 ms of a 95-120 ms batch in this kernel
+  // against 6 ms at c = 10, whose top window is five bits wide).  Rotating the block order by the job index spreads them over the chip.
+  const uint32_t xb = (blockIdx.x + q * 13u) % gridDim.x;
+  const uint32_t b = xb * (64u / LPB) + (threadIdx.x / LPB) + 1;
   const bool live = b <= B;
   const MsmJob job = jobs[q];
   const uint32_t* o = off + (uint64_t)q * (B + 2);
@@ -620,9 +625,13 @@ int g1_canonicalise_multi_dev(zk_ctx* ctx, const CanonRanges& r) {
   return ZK_OK;
 }
 
-uint32_t msm_pick_window(zk_ctx* ctx, uint32_t bits) {
+uint32_t msm_pick_window(zk_ctx* ctx, uint32_t bits, uint32_t n) {
   if (ctx->msm_window) return ctx->msm_window;  // zk_set_msm_window admits 2 .. 13 only
-  return bits <= 24 ? 7 : 10;  // short scalars (quantised weights): two 7-bit windows; full width: 26 x 10 bits
+  if (bits <= 24) return 7;                     // short scalars (quantised weights): two 7-bit windows
+  // full width: the width that leaves 40-50 items per bucket (n W / 2^(c-1)): fewer windows to accumulate while the bucket reduction (2 x 2^(c-1) additions per
+  // MSM) stays a tenth of the accumulation and most buckets still end inside one 64-item chunk.  2^24 pairs (profiles/r04_msm_sweep_phases.txt):
+  //   4096 generators: c = 10 / 11 / 12 / 13: 72.5 / 76.3 / 68.1 / 68.9 ms;   2048 generators: c = 10 / 11 / 12: 78.2 / 73.7 / 76.0 ms
+  return n >= 8192u ? 13 : n >= 4096u ? 12 : n >= 2048u ? 11 : 10;
 }
 uint32_t msm_num_windows(uint32_t bits, uint32_t c) {
   uint32_t W = (bits + 2 + c - 1) / c;  // +2 bits of head-room so mag + K never spills past the top window
@@ -1007,7 +1016,10 @@ static int msm_run_bucket_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs
     // fewer; at <= 2 bits of entropy half of an MSM's points share a handful of buckets -> more lanes per bucket.
     // (Short-scalar batches -- commitments of quantised weights -- keep four lanes: their top window is partial too.)
     const bool full = c * Wmax >= 254u;
-    const bool hot = !full || 256u - c * (Wmax - 1) <= 4u || chunks > 12ull * nj * B;  // or simply many chunks per bucket
+#ifndef ZK_COMBINE_HOT_BIG
+#define ZK_COMBINE_HOT_BIG 1
+#endif
+    const bool hot = (!full || 256u - c * (Wmax - 1) <= 4u || chunks > 12ull * nj * B) && (ZK_COMBINE_HOT_BIG || chunk < 64u);  // or simply many chunks per bucket
     if (hot)
       ZK_LAUNCH(ctx, "msm_combine", (uint64_t)sizeof(G1X) * nj * B, k_msm_combine<4>, dim3((B + 15) / 16, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, chunk, (const uint32_t*)off.get(),
                 buckets.get(), (const G1X*)head.get(), (const G1X*)tail.get());
@@ -1055,7 +1067,8 @@ int msm_enqueue(zk_ctx* ctx, zk_gens* g, const Fr* scalars, uint32_t q, bool do_
     queue->keep.push_back(std::move(mags));
     return ZK_OK;
   }
-  uint32_t c = msm_pick_window(ctx, bits);
+  uint32_t c = msm_pick_window(ctx, bits, n);
+  if (!ctx->msm_window && bits > 24 && queue->c >= 10) c = queue->c;  // one window width per deferred batch: the first full-width job decides
   uint32_t W = msm_num_windows(bits, c);
   if (queue->c != 0 && queue->c != c) {  // one window width per batch
     if (ctx->stream != ctx->main_stream) return ctx->fail(ZK_ERR_ARG, "MSM: window width changed inside a deferred batch");
