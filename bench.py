@@ -300,7 +300,7 @@ def msm_fullwidth_probe(zk, log_pairs=24, full_tables=0):
     del out, sc
     g.close()
     return {"pairs": n * q, "n_gens": n, "msms": q, "ms": ms, "mops": n * q / ms / 1e3, "scalars": "uniform 255-bit",
-            "method": ("precomputed digit tables, window %d bits (no buckets)" % full_tables) if full_tables else "bucket method (Pippenger), 10-bit windows"}
+            "method": ("precomputed digit tables, window %d bits (no buckets)" % full_tables) if full_tables else "bucket method (Pippenger), window width by generator count (11 bits at 2048 generators)"}
 
 
 def spawn_ranks(n, argv):

@@ -1016,10 +1016,7 @@ static int msm_run_bucket_jobs(zk_ctx* ctx, const std::vector<MsmJobHost>& hjobs
     // fewer; at <= 2 bits of entropy half of an MSM's points share a handful of buckets -> more lanes per bucket.
     // (Short-scalar batches -- commitments of quantised weights -- keep four lanes: their top window is partial too.)
     const bool full = c * Wmax >= 254u;
-#ifndef ZK_COMBINE_HOT_BIG
-#define ZK_COMBINE_HOT_BIG 1
-#endif
-    const bool hot = (!full || 256u - c * (Wmax - 1) <= 4u || chunks > 12ull * nj * B) && (ZK_COMBINE_HOT_BIG || chunk < 64u);  // or simply many chunks per bucket
+    const bool hot = !full || 256u - c * (Wmax - 1) <= 4u || chunks > 12ull * nj * B;  // or simply many chunks per bucket
     if (hot)
       ZK_LAUNCH(ctx, "msm_combine", (uint64_t)sizeof(G1X) * nj * B, k_msm_combine<4>, dim3((B + 15) / 16, nj), dim3(64), 0, (const MsmJob*)djobs.get(), c, chunk, (const uint32_t*)off.get(),
                 buckets.get(), (const G1X*)head.get(), (const G1X*)tail.get());
