@@ -5,6 +5,7 @@ import struct
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -25,11 +26,21 @@ def test_round_challenges_follow_the_documented_hash_chain():
     from zkdl_amd.capi import fs_round_challenges
     rng = np.random.default_rng(3)
     seed = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
+    def canonical(rows):                                     # round messages are field elements: below r (top limb below r's top limb is enough)
+        c = rng.integers(0, 1 << 32, size=(rows, 8), dtype=np.uint64).astype(np.uint32)
+        c[:, 7] %= np.uint32(1944954707)
+        return c
     for k in (0, 1, 2, 11, 24):
-        coeffs = rng.integers(0, 1 << 32, size=(3 * k, 8), dtype=np.uint64).astype(np.uint32)
+        coeffs = canonical(3 * k)
         got = fs_round_challenges(seed, 5, 1, 2, coeffs)
         assert np.array_equal(got, model(seed, 5, 1, 2, coeffs)), k
-    coeffs = rng.integers(0, 1 << 32, size=(9, 8), dtype=np.uint64).astype(np.uint32)
+    coeffs = canonical(9)
+    # c and c + r are the same field element but different hash inputs: an unreduced message is refused, not hashed
+    from zkdl_amd.capi import ZkError
+    bad = coeffs.copy()
+    bad[2, :] = 0xffffffff
+    with pytest.raises(ZkError):
+        fs_round_challenges(seed, 0, 0, 0, bad)
     base = fs_round_challenges(seed, 0, 0, 0, coeffs)
     # a changed round message changes that round's challenge and every later one, and nothing before it
     c2 = coeffs.copy()

@@ -369,6 +369,34 @@ def test_msm_window_sweep_gives_same_points(zk, oracle, rng, window):
         zk.set_msm_window(0)
 
 
+@pytest.mark.parametrize("n", [2048, 4096])
+def test_full_width_msm_batch_is_the_same_group_element_at_every_window_width(zk, oracle, rng, n):
+    """Full-width scalars over 2048 / 4096 generators, 40 MSMs in one batch: the width the library picks by generator count (11 / 12 bits) and the forced widths
+    10 .. 13 give the same points.  At 11 and 12 bits the partial top window crowds a quarter to a half of each MSM's points into a few buckets -- the
+    chains k_msm_combine's rotated block order spreads over the chip.  One row is checked against the literal (reference-shaped) MSM."""
+    from zkdl_amd.capi import MSM_PIPPENGER
+    q = 40
+    base = zk.upload(rand_points(oracle, rng, 1))
+    pts = zk.g1_mul(zk.g1_fill(n, base.download()[0]), zk.fr_random(n))
+    gens = zk.gens(pts)
+    sc = zk.fr_random(n * q)
+    zk.set_msm_mode(MSM_PIPPENGER)
+    ref = None
+    try:
+        for w in (0, 10, 11, 12, 13):
+            zk.set_msm_window(w)
+            aff, inf = zk.g1_to_affine(zk.msm_batch(gens, sc))
+            key = (aff.tobytes(), inf.tobytes())
+            ref = ref or key
+            assert key == ref, w
+        zk.set_msm_window(0)
+        la, li = zk.g1_to_affine(zk.upload(zk.g1_sum(zk.g1_mul(pts, sc.view(0, n))).reshape(1, 36)))   # the reference's shape: elementwise products, then the tree sum
+        pa, pi = zk.g1_to_affine(zk.msm_batch(gens, sc.view(0, n)))
+        assert eq(la, pa) and eq(li, pi)
+    finally:
+        zk.set_msm_window(0)
+
+
 def test_msm_window_outside_the_supported_range_is_refused(zk):
     """The counting sort holds one LDS counter per bucket: windows of 2 .. 13 bits.  Wider ones used to be clamped to 13 silently."""
     from zkdl_amd.capi import ZkError
