@@ -52,6 +52,23 @@ int main() {
       }
       for (int k = 0; k < 18; k++) cols[k] += acc[k];
       show(fs_cols_to_fr(cols));
+    } else if (op == "raw64") {  // the 64-bit columns of k_sc_round29: six products between two carries, the lane's columns cut to 29 bits at the end
+      int n; std::cin >> n;
+      uint64_t acc[18]; memset(acc, 0, sizeof acc);
+      uint64_t cols[18]; memset(cols, 0, sizeof cols);
+      for (int i = 0; i < n; i++) {
+        std::string a, b; std::cin >> a >> b;
+        Fs x = fs_unpack(parse(a)), y = fs_unpack(parse(b));
+        fs_mul_raw_acc64(acc, fs_norm(fs_sub<2>(x, y)), y);
+        if (i % 6 == 5) fs_cols_norm64(acc);
+        if ((i & 63) == 63) {
+          fs_cols_norm64(acc);
+          for (int k = 0; k < 18; k++) { cols[k] += (uint32_t)acc[k]; if (acc[k] >> 32) printf("wide!"); acc[k] = 0; }
+        }
+      }
+      fs_cols_norm64(acc);
+      for (int k = 0; k < 18; k++) { cols[k] += (uint32_t)acc[k]; if (acc[k] >> 32) printf("wide!"); }
+      show(fs_cols_to_fr(cols));
     } else if (op == "pair") {  // one pair of a weighted round, as k_sc_round29 computes it: bin c0 c1 c2, hp c0 S c2
       std::string h[6];
       for (auto& x : h) std::cin >> x;

@@ -62,12 +62,13 @@ def test_weighted_pair_coefficients(exe):
         assert got == [x % R_MOD for x in want]
 
 
-@pytest.mark.parametrize("n", [1, 7, 8, 9, 64, 200, 2048])
-def test_unreduced_accumulation(exe, n):
+@pytest.mark.parametrize("op", ["raw", "raw64"])        # 32-bit columns cut per product / 64-bit columns across products (what k_sc_round29 keeps per lane)
+@pytest.mark.parametrize("n", [1, 6, 7, 8, 9, 64, 200, 2048])
+def test_unreduced_accumulation(exe, n, op):
     rng = random.Random(n)
     a, b = vals(rng, n), vals(rng, n)
     if n == 2048:       # the largest total a workgroup accumulates: every operand at its bound
         a, b = [R_MOD - 1] * n, [1] * (n // 2) + [R_MOD - 1] * (n // 2)
-    line = "raw %d " % n + " ".join("%x %x" % t for t in zip(a, b))
+    line = "%s %d " % (op, n) + " ".join("%x %x" % t for t in zip(a, b))
     got = run(exe, [line])
     assert got == [sum((x - y) * y for x, y in zip(a, b)) * RINV % R_MOD]

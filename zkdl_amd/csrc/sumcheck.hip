@@ -218,11 +218,11 @@ __device__ __forceinline__ void k_sc_round29(uint32_t zk_nblk, const Fr* __restr
   Fs ONE;
 #pragma unroll
   for (int i = 0; i < 9; i++) ONE.v[i] = fs29::ONE(i);
-  uint32_t acc[3][18];
+  uint64_t acc64[3][18];  // 64-bit columns across the lane's pairs (fs_mul_raw_acc64): cut back to 29 bits every fourth pair
 #pragma unroll
   for (int q = 0; q < 3; q++)
 #pragma unroll
-    for (int k = 0; k < 18; k++) acc[q][k] = 0;
+    for (int k = 0; k < 18; k++) acc64[q][k] = 0;
   // factored weights: see k_sc_round
   uint32_t P = 0;
   bool fact = false;
@@ -262,28 +262,28 @@ __device__ __forceinline__ void k_sc_round29(uint32_t zk_nblk, const Fr* __restr
       }
       if (MODE == SC_BIN) {
         const Fs A0W = fs_mul(A0, W), DAW = fs_mul(DA, W);                 // < 1.7, < 3
-        fs_mul_raw_acc(acc[0], A0W, fs_norm(fs_sub<2>(A0, ONE)));           // a0 - 1: < 3
-        fs_mul_raw_acc(acc[1], DAW, fs_norm(fs_sub<2>(fs_add(A0, A0), ONE)));  // 2 a0 - 1: < 4
-        fs_mul_raw_acc(acc[2], DAW, DA);
+        fs_mul_raw_acc64(acc64[0], A0W, fs_norm(fs_sub<2>(A0, ONE)));           // a0 - 1: < 3
+        fs_mul_raw_acc64(acc64[1], DAW, fs_norm(fs_sub<2>(fs_add(A0, A0), ONE)));  // 2 a0 - 1: < 4
+        fs_mul_raw_acc64(acc64[2], DAW, DA);
       } else {
         const Fs B0 = fs_unpack(e0 < in_size ? b[e0] : zero), B1 = fs_unpack(e1 < in_size ? b[e1] : zero);
         const Fs DB = fs_norm(fs_sub<2>(B1, B0));
         if (MODE == SC_HP) {
           const Fs A0W = fs_mul(A0, W), DAW = fs_mul(DA, W);
-          fs_mul_raw_acc(acc[0], A0W, B0);
-          fs_mul_raw_acc(acc[1], fs_norm(fs_add(A0W, DAW)), B1);  // < 4.7
-          fs_mul_raw_acc(acc[2], DAW, DB);
+          fs_mul_raw_acc64(acc64[0], A0W, B0);
+          fs_mul_raw_acc64(acc64[1], fs_norm(fs_add(A0W, DAW)), B1);  // < 4.7
+          fs_mul_raw_acc64(acc64[2], DAW, DB);
         } else {
-          fs_mul_raw_acc(acc[0], A0, B0);
-          fs_mul_raw_acc(acc[1], A1, B1);
-          fs_mul_raw_acc(acc[2], DA, DB);
+          fs_mul_raw_acc64(acc64[0], A0, B0);
+          fs_mul_raw_acc64(acc64[1], A1, B1);
+          fs_mul_raw_acc64(acc64[2], DA, DB);
         }
         b_out[g] = fs_to_fr(fs_norm(fs_add(B0, fs_mul(X, DB))));  // < 1 + 2.4
       }
       a_out[g] = fs_to_fr(fs_norm(fs_add(A0, fs_mul(X, DA))));
       if ((++it & 3u) == 0) {
 #pragma unroll
-        for (int q = 0; q < 3; q++) fs_cols_norm(acc[q]);
+        for (int q = 0; q < 3; q++) fs_cols_norm64(acc64[q]);
       }
     }
   };
@@ -291,8 +291,13 @@ __device__ __forceinline__ void k_sc_round29(uint32_t zk_nblk, const Fr* __restr
   else sweep(std::false_type{});
   // ---- the three column sets, lane -> workgroup, as plain integers: two DPP steps inside each quad (columns < 2^29 after
   // the carry, so a quad's sum fits 32 bits), one lane per quad to LDS, 54 lanes add a column each over the 64 quads.
+  uint32_t acc[3][18];
 #pragma unroll
-  for (int q = 0; q < 3; q++) fs_cols_norm(acc[q]);
+  for (int q = 0; q < 3; q++) {
+    fs_cols_norm64(acc64[q]);
+#pragma unroll
+    for (int k = 0; k < 18; k++) acc[q][k] = (uint32_t)acc64[q][k];  // < 2^29 each (the top one: the whole sum / 2^493 < 2^25)
+  }
 #pragma unroll
   for (int q = 0; q < 3; q++)
 #pragma unroll
