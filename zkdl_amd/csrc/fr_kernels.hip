@@ -10,6 +10,7 @@
 // 2^c-entry eq-weight table of those c challenges (built on device by k_eq_table).
 #include "ctx.hpp"
 #include "dev_util.hpp"
+#include "fs29.hpp"
 
 namespace zk {
 
@@ -114,45 +115,69 @@ __device__ __forceinline__ void k_eq_table(uint32_t zk_nblk, const Fr* __restric
 }
 
 // out[h*W + w] = sum_{m<M} E[m] * t[(h*M + m)*W + w]   (zero beyond n); one thread per output.
-// HBM-streaming: the row loop is unrolled so that several 32-byte loads per lane are in flight.
+// A term is NOT a Montgomery product plus a modular addition (~360 instructions in the 32-bit-limb form): both operands go to nine 29-bit limbs and their
+// 81 partial products land in 64-bit columns that live across the whole loop (fs29.hpp: fs_mul_raw_acc64; carries every sixth term), and the sum is
+// reduced ONCE per output (fs_cols_to_fr: T / 2^256 mod r, canonical -- the value sum_m fr_mul(E[m], t[..]) has, so the transcript is bit-identical).
+// ~120 instructions per term; the row loop keeps six 32-byte loads in flight.  E[m] is uniform over the wave: scalar loads, unpacked on the scalar unit.
 __device__ __forceinline__ void k_colsum(uint32_t zk_nblk, const Fr* __restrict__ t, uint32_t n, const Fr* __restrict__ E, uint32_t M, uint32_t W,
                                                  uint32_t total_out, Fr* __restrict__ out) {
   for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total_out; idx += zk_nblk * blockDim.x) {
-    uint32_t h = idx / W, w = idx - h * W;
-    Fr acc = fr_zero();
-    uint64_t base = (uint64_t)h * M * W + w;
+    const uint32_t h = idx / W, w = idx - h * W;
+    const uint64_t base = (uint64_t)h * M * W + w;
+    uint64_t acc[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) acc[k] = 0;
     uint32_t m = 0;
-    for (; m + 4 <= M && base + (uint64_t)(m + 3) * W < n; m += 4) {
-      Fr v0 = t[base + (uint64_t)m * W], v1 = t[base + (uint64_t)(m + 1) * W], v2 = t[base + (uint64_t)(m + 2) * W], v3 = t[base + (uint64_t)(m + 3) * W];
-      acc = fr_add(acc, fr_add(fr_add(fr_mul(E[m], v0), fr_mul(E[m + 1], v1)), fr_add(fr_mul(E[m + 2], v2), fr_mul(E[m + 3], v3))));
+    for (; m + 6 <= M && base + (uint64_t)(m + 5) * W < n; m += 6) {
+      Fr v[6];
+#pragma unroll
+      for (int q = 0; q < 6; q++) v[q] = t[base + (uint64_t)(m + q) * W];
+#pragma unroll
+      for (int q = 0; q < 6; q++) fs_mul_raw_acc64(acc, fs_unpack(E[m + q]), fs_unpack(v[q]));
+      fs_cols_norm64(acc);
     }
-    for (; m < M; m++) {
-      uint64_t src = base + (uint64_t)m * W;
-      if (src < n) acc = fr_add(acc, fr_mul(E[m], t[src]));
+    for (; m < M; m++) {  // at most five terms in range (rows beyond n are zero)
+      const uint64_t src = base + (uint64_t)m * W;
+      if (src < n) fs_mul_raw_acc64(acc, fs_unpack(E[m]), fs_unpack(t[src]));
     }
-    out[idx] = acc;
+    fs_cols_norm64(acc);
+    out[idx] = fs_cols_to_fr(acc);
   }
 }
-// W == 1, M >= 64: one WAVE per output h (four per workgroup); lanes stride the contiguous row, four loads in
-// flight, and the only reduction is the wave's shuffle ladder (no LDS stage, no barriers).
+// W == 1, M >= 64: one WAVE per output h (four per workgroup); lanes stride the contiguous row, four loads in flight; each lane keeps its own 64-bit
+// columns, the wave adds them as plain integers by shuffles, and lane 0 reduces once (no LDS stage, no barriers).
 __device__ __forceinline__ void k_dot_block(uint32_t zk_nblk, const Fr* __restrict__ t, uint32_t n, const Fr* __restrict__ E, uint32_t M, Fr* __restrict__ out,
                                                     uint32_t H) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t h = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (h >= H) return;
-  uint64_t base = (uint64_t)h * M;
-  Fr acc = fr_zero();
+  const uint64_t base = (uint64_t)h * M;
+  uint64_t acc[18];
+#pragma unroll
+  for (int k = 0; k < 18; k++) acc[k] = 0;
   uint32_t m = lane;
   for (; m + 192 < M && base + m + 192 < n; m += 256) {
-    Fr v0 = t[base + m], v1 = t[base + m + 64], v2 = t[base + m + 128], v3 = t[base + m + 192];
-    acc = fr_add(acc, fr_add(fr_add(fr_mul(E[m], v0), fr_mul(E[m + 64], v1)), fr_add(fr_mul(E[m + 128], v2), fr_mul(E[m + 192], v3))));
+    Fr v[4], e[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      v[q] = t[base + m + 64 * q];
+      e[q] = E[m + 64 * q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) fs_mul_raw_acc64(acc, fs_unpack(e[q]), fs_unpack(v[q]));
+    fs_cols_norm64(acc);
   }
-  for (; m < M; m += 64) {
-    uint64_t src = base + m;
-    if (src < n) acc = fr_add(acc, fr_mul(E[m], t[src]));
+  for (; m < M; m += 64) {  // at most three terms per lane
+    const uint64_t src = base + m;
+    if (src < n) fs_mul_raw_acc64(acc, fs_unpack(E[m]), fs_unpack(t[src]));
   }
-  acc = wave_sum_fr(acc);
-  if (lane == 0) out[h] = acc;
+  fs_cols_norm64(acc);  // columns < 2^29 (the top one: the lane's whole sum / 2^493): 64 lanes add without overflow
+#pragma unroll
+  for (int k = 0; k < 18; k++) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off, 64);
+  }
+  if (lane == 0) out[h] = fs_cols_to_fr(acc);
 }
 
 static int eq_table(zk_ctx* ctx, const Fr* u_d, uint32_t c, Fr* E) {
