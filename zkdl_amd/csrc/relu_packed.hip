@@ -500,17 +500,32 @@ __device__ __forceinline__ void k_binb_words(uint32_t zk_nblk, const WordT* __re
   for (uint32_t i = threadIdx.x; i < NBINS * BINB_LIMBS_LDS; i += blockDim.x) dst[i] = H[i];
 }
 
-// sums[i] = (low 64 bits, carries) of sum over the slabs of counter i
+// sums[i] = (low 64 bits, carries) of sum over the slabs of counter i.  Eight lanes share a counter (each adds every eighth slab, three shuffle steps join
+// them): the launch is a chain of dependent-latency loads on the bit sumchecks' streams (one lane per counter walked all 56 slabs of a 453 888-word
+// tensor: 65 us), not bandwidth (6 MB).
+static constexpr uint32_t BINB_REDUCE_LANES = 8;
 __device__ __forceinline__ void k_binb_reduce(uint32_t zk_nblk, const unsigned long long* __restrict__ slabs, uint32_t nslab, uint32_t ncount, unsigned long long* __restrict__ sums) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ncount; i += zk_nblk * blockDim.x) {
+  const uint32_t sub = threadIdx.x % BINB_REDUCE_LANES, per_blk = blockDim.x / BINB_REDUCE_LANES;
+  for (uint32_t base = blockIdx.x * per_blk; base < ncount; base += zk_nblk * per_blk) {  // uniform over the workgroup: every lane takes part in the shuffles
+    const uint32_t i = base + threadIdx.x / BINB_REDUCE_LANES;
     unsigned long long lo = 0, hi = 0;
-    for (uint32_t sl = 0; sl < nslab; sl++) {
-      const unsigned long long x = slabs[(size_t)sl * ncount + i];
-      lo += x;
-      hi += lo < x ? 1ull : 0ull;
+    if (i < ncount) {
+      for (uint32_t sl = sub; sl < nslab; sl += BINB_REDUCE_LANES) {
+        const unsigned long long x = slabs[(size_t)sl * ncount + i];
+        lo += x;
+        hi += lo < x ? 1ull : 0ull;
+      }
     }
-    sums[2 * (size_t)i] = lo;
-    sums[2 * (size_t)i + 1] = hi;
+#pragma unroll
+    for (uint32_t m = 1; m < BINB_REDUCE_LANES; m <<= 1) {
+      const unsigned long long olo = __shfl_xor(lo, m, 64), ohi = __shfl_xor(hi, m, 64);
+      lo += olo;
+      hi += ohi + (lo < olo ? 1ull : 0ull);
+    }
+    if (i < ncount && sub == 0) {
+      sums[2 * (size_t)i] = lo;
+      sums[2 * (size_t)i + 1] = hi;
+    }
   }
 }
 
@@ -680,7 +695,7 @@ int binb_sumcheck_pme_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t 
     ZK_LAUNCHB(ctx, "binp_words", bytes, 1024, (k_binb_words<16, uint16_t>), dim3(grid), lds, (const uint16_t*)packed, n, (const Fr*)tab.get(), (const Fr*)AH.get(), (const Fr*)BH.get(), ch,
               v_d, out.get(), partialA.get(), slabs.get(), (const Fr*)A2.get(), (const Fr*)B2.get(), ch);
   }
-  ZK_LAUNCHB(ctx, "binp_finish", 8ull * grid * ncount, 256, k_binb_reduce, dim3(stream_grid(ncount, 256, 32)), 0, (const unsigned long long*)slabs.get(), grid, ncount, sums.get());
+  ZK_LAUNCHB(ctx, "binp_finish", 8ull * grid * ncount, 256, k_binb_reduce, dim3(stream_grid(ncount * BINB_REDUCE_LANES, 256, 128)), 0, (const unsigned long long*)slabs.get(), grid, ncount, sums.get());
   ZK_LAUNCHB(ctx, "binp_finish", 16ull * ncount + 32ull * L.nH * L.NF, 1024, k_binb_finish, dim3(1), 0, (const unsigned long long*)sums.get(), (const Fr*)fac.get(),
             (const Fr*)tab.get(), (const Fr*)partialA.get(), nb == 32 ? grid : 0u, L, u_d, v_d, proof_d, pme_d);
   // rounds R .. k-1 and the final a(0): generic path on the table of one element per word
@@ -1114,7 +1129,7 @@ int fsb_sumcheck_head_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t 
     ZK_LAUNCHB(ctx, "fs_bit_hist", bytes, 1024, (k_fsb_hist<16, uint16_t>), dim3(grid), lds, p16, n, (const Fr*)AH.get(), (const Fr*)BH.get(), ch, (const Fr*)A2.get(), (const Fr*)B2.get(), ch,
               slabs.get());
   }
-  ZK_LAUNCHB(ctx, "binp_finish", 8ull * grid * ncount, 256, k_binb_reduce, dim3(stream_grid(ncount, 256, 32)), 0, (const unsigned long long*)slabs.get(), grid, ncount, sums.get());
+  ZK_LAUNCHB(ctx, "binp_finish", 8ull * grid * ncount, 256, k_binb_reduce, dim3(stream_grid(ncount * BINB_REDUCE_LANES, 256, 128)), 0, (const unsigned long long*)slabs.get(), grid, ncount, sums.get());
   // ---- rounds 0, 1, 2 (one workgroup, hashing between them); leaves x_0..x_2, V3 and the normalised histogram
   ZK_LAUNCHB(ctx, "fs_bit_rounds", 16ull * ncount, 1024, k_fsb_rounds, dim3(1), 0, (const unsigned long long*)sums.get(), L, u_d, fold_d, state, proof_d, pme_d, v3tab.get(), hfr.get());
   // ---- round 3: the byte pairs' cross terms need V3
@@ -1123,7 +1138,7 @@ int fsb_sumcheck_head_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t 
   } else {
     ZK_LAUNCHB(ctx, "fs_bit_hist", bytes, 1024, (k_fsb_cross<16, uint16_t>), dim3(grid), xlds, p16, n, (const Fr*)AH.get(), (const Fr*)BH.get(), ch, (const Fr*)v3tab.get(), xslabs.get());
   }
-  ZK_LAUNCHB(ctx, "binp_finish", 8ull * grid * xcount, 256, k_binb_reduce, dim3(stream_grid(xcount, 256, 32)), 0, (const unsigned long long*)xslabs.get(), grid, xcount, xsums.get());
+  ZK_LAUNCHB(ctx, "binp_finish", 8ull * grid * xcount, 256, k_binb_reduce, dim3(stream_grid(xcount * BINB_REDUCE_LANES, 256, 128)), 0, (const unsigned long long*)xslabs.get(), grid, xcount, xsums.get());
   ZK_LAUNCHB(ctx, "fs_bit_rounds", 16ull * xcount + 32ull * L.nH, 1024, k_fsb_round3, dim3(1), 0, (const Fr*)hfr.get(), (const unsigned long long*)xsums.get(), L, u_d, (const Fr*)v3tab.get(), fold_d + 3,
             state, proof_d + 9, tabAB.get(), sx.get());
   // ---- round 4 (32-bit words): the product of a word's two halves needs x_3
