@@ -355,7 +355,8 @@ __device__ __forceinline__ void binb_factors(uint32_t p, uint32_t e, const Fr* _
 // tables for k_binb_words ([V3 | VA = (1 - v3) V3 | VB = v3 V3], 768 entries), the two-level word weights and the per-bin
 // factors -- one launch; workgroups [0, nH / 256) do the factors (one bin per lane), the rest everything else
 __device__ __forceinline__ void k_binb_prep(uint32_t zk_nblk, const Fr* __restrict__ u, const Fr* __restrict__ v, uint32_t k, BytesLayout L, uint32_t ch, Fr* __restrict__ tab,
-                                                    Fr* __restrict__ AH, Fr* __restrict__ BH, Fr* __restrict__ fac) {
+                                                    Fr* __restrict__ AH, Fr* __restrict__ BH, Fr* __restrict__ fac, const Fr* __restrict__ u_rec, Fr* __restrict__ A2,
+                                                    Fr* __restrict__ B2) {
   __shared__ Fr elo[30 + 8];
   const uint32_t nfb = L.nH / 256;  // factor workgroups (blockDim.x = 256)
   if (threadIdx.x < 38) {           // every workgroup needs eqv; the factor workgroups also the position weights
@@ -377,7 +378,8 @@ __device__ __forceinline__ void k_binb_prep(uint32_t zk_nblk, const Fr* __restri
     return;
   }
   const uint32_t nAH = 1u << ch, nBH = 1u << (k - L.lognb - ch);
-  const uint32_t o1 = 768, o2 = o1 + nAH, total = o2 + nBH;
+  // (u_rec != nullptr: the two-level eq(u_rec, .) tables of the partial_me histogram as well -- they were a launch of their own at the head of the chain)
+  const uint32_t o1 = 768, o2 = o1 + nAH, o3 = o2 + nBH, o4 = u_rec ? o3 + nAH : o3, total = u_rec ? o4 + nBH : o3;
   for (uint32_t idx = (blockIdx.x - nfb) * blockDim.x + threadIdx.x; idx < total; idx += (zk_nblk - nfb) * blockDim.x) {
     if (idx < o1) {
       const uint32_t e = idx & 255u, which = idx >> 8;
@@ -388,8 +390,12 @@ __device__ __forceinline__ void k_binb_prep(uint32_t zk_nblk, const Fr* __restri
       tab[idx] = which == 0 ? t : which == 1 ? fr_mul(fr_sub(fr_one(), v[3]), t) : fr_mul(v[3], t);
     } else if (idx < o2) {
       AH[idx - o1] = eq_prod(u + L.lognb, ch, idx - o1);
-    } else {
+    } else if (idx < o3) {
       BH[idx - o2] = eq_prod(u + L.lognb + ch, k - L.lognb - ch, idx - o2);
+    } else if (idx < o4) {
+      A2[idx - o3] = eq_prod(u_rec, ch, idx - o3);
+    } else {
+      B2[idx - o4] = eq_prod(u_rec + ch, k - L.lognb - ch, idx - o4);
     }
   }
 }
@@ -659,17 +665,13 @@ int binb_sumcheck_pme_dev(zk_ctx* ctx, const void* packed, uint32_t n, uint32_t 
   const uint32_t nbins = L.nH + L.nHP + L.nH, ncount = nbins * BINB_LIMBS_LDS;
   ZK_ALLOC(ctx, A2, Fr, (size_t)1 << ch);
   ZK_ALLOC(ctx, B2, Fr, (size_t)1 << (kh - ch));
-  {
-    const uint32_t nt = (1u << ch) + (1u << (kh - ch));
-    ZK_LAUNCHB(ctx, "binp_prep", 32ull * nt, 256, k_eq_pair_tables, dim3(stream_grid(nt, 256, 16)), 0, u_rec_d, kh, ch, A2.get(), B2.get());
-  }
   ZK_ALLOC(ctx, tab, Fr, 768);
   ZK_ALLOC(ctx, AH, Fr, (size_t)1 << ch);
   ZK_ALLOC(ctx, BH, Fr, (size_t)1 << (kh - ch));
   ZK_ALLOC(ctx, fac, Fr, (size_t)L.nH * L.NF);
-  const uint32_t nrest = 768 + (1u << ch) + (1u << (kh - ch));
+  const uint32_t nrest = 768 + 2 * ((1u << ch) + (1u << (kh - ch)));   // the tables, the word weights and the partial_me weights: one launch
   ZK_LAUNCHB(ctx, "binp_prep", 32ull * (nrest + L.nH * L.NF), 256, k_binb_prep, dim3(L.nH / 256 + stream_grid(nrest, 256, 16)), 0, u_d, v_d, k, L, ch, tab.get(), AH.get(), BH.get(),
-            fac.get());
+            fac.get(), u_rec_d, A2.get(), B2.get());
   // one workgroup (1024 lanes) per BINB_WORDS_PER_WG words: few enough that no 64-bit counter can overflow, many enough to amortise
   // the workgroup's histogram set-up and flush
   const uint32_t grid = (n + BINB_WORDS_PER_WG - 1) / BINB_WORDS_PER_WG;
